@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ fixtures by RUNNING THE COMPILED REFERENCE (oracle/_ref/ref_hnsw, built by
+oracle/Makefile from /root/reference/third_party/hnswlib as-is).  Run in the build container only;
+the outputs (data, not source) are committed so the GPU box never needs /root/reference.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hsutil import GOLDEN, ROOT, mixture, read_ref_search, write_fvecs  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_hnsw")
+
+
+def run(*args):
+    subprocess.check_call([REF, *map(str, args)])
+
+
+def dist_fixture(tmp):
+    out = {}
+    rng = np.random.default_rng(20250101)
+    for metric, dims in (("l2", [3, 7, 16, 20, 23, 96, 100, 128, 768, 960]), ("ip", [16, 96, 128, 768, 960])):
+        for d in dims:
+            n = 64 if d <= 128 else 16
+            a = (rng.standard_normal((n, d)) * 3).astype(np.float32)
+            b = (rng.standard_normal((n, d)) * 3).astype(np.float32)
+            if d == 128:  # SIFT-like integer rows too
+                a[: n // 2] = np.clip(np.rint(a[: n // 2] * 30 + 100), 0, 255)
+                b[: n // 2] = np.clip(np.rint(b[: n // 2] * 30 + 100), 0, 255)
+            fa, fb, fo = (os.path.join(tmp, f"{x}.bin") for x in "abo")
+            write_fvecs(fa, a)
+            write_fvecs(fb, b)
+            run("dist", metric, fa, fb, fo)
+            out[f"{metric}_{d}_a"] = a
+            out[f"{metric}_{d}_b"] = b
+            out[f"{metric}_{d}_ref"] = np.fromfile(fo, np.float32)
+    np.savez_compressed(os.path.join(GOLDEN, "dist_ref.npz"), **out)
+
+
+def index_fixture(tmp, name, metric, base, queries, M, efC, efs, k=10):
+    fb, fq = os.path.join(tmp, "b.fvecs"), os.path.join(tmp, "q.fvecs")
+    write_fvecs(fb, base)
+    write_fvecs(fq, queries)
+    idx = os.path.join(GOLDEN, f"{name}.hnsw.bin")
+    run("build", metric, fb, idx, M, efC, "4", 100)
+    res = os.path.join(tmp, "res.bin")
+    run("search", metric, idx, fq, res, k, *efs)
+    parsed = read_ref_search(res)
+    out = {"base": base, "queries": queries, "efs": np.array(efs), "k": np.array(k), "M": np.array(M), "efC": np.array(efC)}
+    for ef, r in parsed.items():
+        for key, v in r.items():
+            out[f"ef{ef}_{key}"] = v
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **out)
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        dist_fixture(tmp)
+        # continuous (tie-free) L2, d=32
+        index_fixture(tmp, "l2_cont_d32", "l2", mixture(2000, 32, 1), mixture(100, 32, 2), 8, 100, [10, 32, 64])
+        # integer-valued (tie-heavy) L2, d=16, tiny value range -> many equal distances
+        bi = mixture(2000, 16, 3, lo=2, hi=8, sigma=2.0, integer=True)
+        qi = mixture(100, 16, 4, lo=2, hi=8, sigma=2.0, integer=True)
+        index_fixture(tmp, "l2_int_d16", "l2", bi, qi, 8, 100, [10, 32, 64])
+        # inner product, normalised rows, d=48
+        b = mixture(1500, 48, 5, lo=-1, hi=1, sigma=0.5)
+        q = mixture(100, 48, 6, lo=-1, hi=1, sigma=0.5)
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        index_fixture(tmp, "ip_d48", "ip", b.astype(np.float32), q.astype(np.float32), 8, 100, [10, 48])
+    print("golden fixtures written to", GOLDEN)
+
+
+if __name__ == "__main__":
+    main()

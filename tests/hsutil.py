@@ -1,0 +1,178 @@
+"""Shared helpers for tests/bench: fvecs IO, seeded synthetic data, ctypes loaders.
+
+The oracle loader lives here (tests only); the product binding lives in hnsw-slim_amd/__init__.py.
+"""
+import ctypes
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def write_fvecs(path, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, d = x.shape
+    out = np.empty((n, d + 1), dtype=np.float32)
+    out[:, 0] = np.frombuffer(np.int32(d).tobytes(), dtype=np.float32)[0]
+    out[:, 1:] = x
+    out.tofile(path)
+
+
+def read_fvecs(path):
+    raw = np.fromfile(path, dtype=np.float32)
+    d = int(raw[:1].view(np.int32)[0])
+    return np.ascontiguousarray(raw.reshape(-1, d + 1)[:, 1:])
+
+
+def mixture(n, d, seed, n_clusters=16, lo=20.0, hi=120.0, sigma=25.0, integer=False, centres_seed=7):
+    """Gaussian-mixture rows (SURVEY.md 8d style). integer=True rounds+clips to [0,255] (tie-heavy)."""
+    crng = np.random.default_rng(centres_seed)
+    centres = crng.uniform(lo, hi, size=(n_clusters, d)).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    which = rng.integers(0, n_clusters, size=n)
+    x = centres[which] + rng.standard_normal((n, d)).astype(np.float32) * np.float32(sigma)
+    if integer:
+        x = np.clip(np.rint(x), 0, 255)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def load_product():
+    """Import the product package (directory name has a hyphen, so load it by path)."""
+    name = "hnsw_slim_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "hnsw-slim_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Oracle:
+    """ctypes view of oracle/liboracle.so (CPU restatement; checker only)."""
+
+    def __init__(self):
+        so = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        L = ctypes.CDLL(so)
+        L.hso_last_error.restype = ctypes.c_char_p
+        L.hso_load.restype = ctypes.c_void_p
+        L.hso_load.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+        L.hso_free.argtypes = [ctypes.c_void_p]
+        L.hso_set_ef.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.hso_count.restype = ctypes.c_size_t
+        L.hso_count.argtypes = [ctypes.c_void_p]
+        L.hso_maxlevel.argtypes = [ctypes.c_void_p]
+        vp = ctypes.c_void_p
+        L.hso_slim_search_ids.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_int]
+        L.hso_search_pq.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_int]
+        L.hso_dist.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
+        L.hso_brute_force.argtypes = [ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_int]
+        self.L = L
+
+    def err(self):
+        return self.L.hso_last_error().decode()
+
+    def dist(self, metric, a, b):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        out = np.empty(a.shape[0], np.float32)
+        rc = self.L.hso_dist(metric, a.ctypes.data, b.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data)
+        if rc:
+            raise RuntimeError(self.err())
+        return out
+
+    def brute_force(self, metric, base, q, k, threads=8):
+        base = np.ascontiguousarray(base, np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.empty((q.shape[0], k), np.uint32)
+        self.L.hso_brute_force(metric, base.ctypes.data, base.shape[0], base.shape[1], q.ctypes.data, q.shape[0], k, out.ctypes.data, threads)
+        return out
+
+    def load(self, path, kind, metric, dim):
+        h = self.L.hso_load(path.encode(), {"hnsw": 0, "slim": 1}[kind], metric, dim)
+        if not h:
+            raise RuntimeError(self.err())
+        return OracleIndex(self, h, kind, dim)
+
+
+class OracleIndex:
+    def __init__(self, o, h, kind, dim):
+        self.o, self.h, self.kind, self.dim = o, h, kind, dim
+        self.ef = 10
+
+    def __del__(self):
+        try:
+            self.o.L.hso_free(self.h)
+        except Exception:
+            pass
+
+    @property
+    def count(self):
+        return self.o.L.hso_count(self.h)
+
+    def set_ef(self, ef):
+        self.ef = ef
+        self.o.L.hso_set_ef(self.h, ef)
+
+    def search_ids(self, q, k, threads=1, raw=True):
+        """HierarchicalNSWSlim::searchKnn(q,k,tableint*) -> dict(labels, raw_d, raw_i, raw_sz, counters)."""
+        q = np.ascontiguousarray(q, np.float32)
+        nq = q.shape[0]
+        cap = max(self.ef, k)
+        out = np.zeros((nq, k), np.uint32)
+        rd = np.zeros((nq, cap), np.float32)
+        ri = np.zeros((nq, cap), np.uint32)
+        rs = np.zeros(nq, np.uint32)
+        cn = np.zeros((nq, 5), np.uint32)
+        rc = self.o.L.hso_slim_search_ids(self.h, q.ctypes.data, nq, k, out.ctypes.data, cap, rd.ctypes.data, ri.ctypes.data, rs.ctypes.data, cn.ctypes.data, threads)
+        if rc:
+            raise RuntimeError(self.o.err())
+        return dict(labels=out, raw_d=rd, raw_i=ri, raw_sz=rs, counters=cn)
+
+    def search_pq(self, q, k, threads=1):
+        """priority_queue-returning searchKnn (vanilla or slim): pop order, farthest first."""
+        q = np.ascontiguousarray(q, np.float32)
+        nq = q.shape[0]
+        cap = max(self.ef, k)
+        od = np.zeros((nq, k), np.float32)
+        ol = np.zeros((nq, k), np.uint64)
+        oc = np.zeros(nq, np.uint32)
+        rd = np.zeros((nq, cap), np.float32)
+        ri = np.zeros((nq, cap), np.uint32)
+        rs = np.zeros(nq, np.uint32)
+        cn = np.zeros((nq, 5), np.uint32)
+        rc = self.o.L.hso_search_pq(self.h, q.ctypes.data, nq, k, od.ctypes.data, ol.ctypes.data, oc.ctypes.data, cap, rd.ctypes.data, ri.ctypes.data, rs.ctypes.data, cn.ctypes.data, threads)
+        if rc:
+            raise RuntimeError(self.o.err())
+        return dict(dists=od, labels=ol, cnt=oc, raw_d=rd, raw_i=ri, raw_sz=rs, counters=cn)
+
+
+def read_ref_search(path):
+    """Parse the result file written by oracle/ref_driver.cpp `search`."""
+    buf = open(path, "rb").read()
+    off = 0
+    nq, k, nef = np.frombuffer(buf, np.uint32, 3, off)
+    off += 12
+    out = {}
+    for _ in range(nef):
+        ef = int(np.frombuffer(buf, np.uint32, 1, off)[0]); off += 4
+        dists = np.zeros((nq, k), np.float32)
+        labels = np.zeros((nq, k), np.uint64)
+        cnt = np.zeros(nq, np.uint32)
+        calls = np.zeros(nq, np.uint32)
+        for i in range(nq):
+            c, nc = np.frombuffer(buf, np.uint32, 2, off); off += 8
+            cnt[i], calls[i] = c, nc
+            rec = np.frombuffer(buf, np.dtype([("d", "<f4"), ("l", "<u8")]), c, off); off += 12 * int(c)
+            dists[i, :c] = rec["d"]
+            labels[i, :c] = rec["l"]
+        out[ef] = dict(dists=dists, labels=labels, cnt=cnt, calls=calls)
+    return out

@@ -1,0 +1,52 @@
+"""Pin the CPU restatement (oracle/) against outputs of the COMPILED REFERENCE (tests/golden/*,
+made by tests/golden/make_golden.py from oracle/_ref/ref_hnsw).  CPU-only."""
+import os
+
+import numpy as np
+import pytest
+
+from hsutil import GOLDEN
+
+L2, IP = 0, 1
+
+
+def test_distance_recipes_bit_exact(oracle):
+    g = np.load(os.path.join(GOLDEN, "dist_ref.npz"))
+    checked = 0
+    for key in g.files:
+        if not key.endswith("_ref"):
+            continue
+        metric, d = key.split("_")[:2]
+        if metric == "ip" and int(d) % 16:
+            continue
+        a, b, ref = g[f"{metric}_{d}_a"], g[f"{metric}_{d}_b"], g[key]
+        got = oracle.dist(L2 if metric == "l2" else IP, a, b)
+        assert got.tobytes() == ref.tobytes(), f"{metric} d={d}: restated recipe differs from the reference"
+        checked += 1
+    assert checked >= 14
+
+
+@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48)])
+def test_vanilla_search_matches_reference(oracle, name, metric, dim):
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    ix = oracle.load(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "hnsw", metric, dim)
+    k = int(g["k"])
+    for ef in g["efs"]:
+        ix.set_ef(int(ef))
+        r = ix.search_pq(g["queries"], k)
+        assert np.array_equal(r["cnt"], g[f"ef{ef}_cnt"])
+        # labels and fp32 distances bit-exact, in the reference's priority_queue pop order
+        assert np.array_equal(r["labels"], g[f"ef{ef}_labels"]), f"{name} ef={ef}"
+        assert r["dists"].tobytes() == g[f"ef{ef}_dists"].tobytes()
+        # distance-function call count of the reference == the oracle's n_dist counter
+        assert np.array_equal(r["counters"][:, 0], g[f"ef{ef}_calls"])
+
+
+def test_load_errors(oracle, tmp_path):
+    with pytest.raises(RuntimeError, match="Cannot open file"):
+        oracle.load(str(tmp_path / "nope.bin"), "hnsw", L2, 32)
+    bad = tmp_path / "trunc.bin"
+    data = open(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), "rb").read()
+    bad.write_bytes(data[: len(data) // 2])
+    with pytest.raises(RuntimeError, match="corrupted"):
+        oracle.load(str(bad), "hnsw", L2, 32)
