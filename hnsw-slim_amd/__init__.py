@@ -1,0 +1,181 @@
+"""hnsw_slim_amd -- thin ctypes binding over the C ABI (include/hnsw_slim_amd.h) of the MI355X-native
+HNSW / HNSW-Slim batched search engine.  Used by tests/ and bench.py; the drop-in surface for C++
+callers is hnsw-slim_amd/hnswlib/hnswlib_amd.h.
+
+There is no CPU search path here: if the HIP library is missing or no device is visible, index
+loading / searching raises (fails loudly) instead of falling back.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhnsw_slim_amd.so")
+
+HS_KIND_HNSW, HS_KIND_SLIM = 0, 1
+HS_METRIC_L2, HS_METRIC_IP = 0, 1
+HS_MODE_SLIM_IDS, HS_MODE_PQ = 0, 1
+HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORTED, HS_ERR_DEVICE, HS_ERR_CAPACITY = range(8)
+
+EXPORTS = [
+    "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
+    "hs_set_capacity", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw",
+    "hs_build_hnsw", "hs_convert_slim",
+]
+
+
+class HsError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(msg)
+        self.status = status
+
+
+class HsInfo(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("dim", ctypes.c_uint64), ("kind", ctypes.c_int32), ("metric", ctypes.c_int32),
+                ("maxlevel", ctypes.c_int32), ("threshold_level", ctypes.c_int32), ("enterpoint", ctypes.c_uint32),
+                ("has_deleted", ctypes.c_int32), ("n_edges", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64),
+                ("max_degree0", ctypes.c_uint64)]
+
+
+def build_library(force=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "libhnsw_slim_amd.so"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HsError(HS_ERR_DEVICE, f"{LIB_PATH} is missing: build it with `make -C hnsw-slim_amd` "
+                      "(__graft_entry__.build()); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
+    L.hs_last_error.restype = ctypes.c_char_p
+    L.hs_device_count.restype = ci
+    L.hs_index_load.argtypes = [ctypes.c_char_p, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
+    L.hs_index_free.argtypes = [vp]
+    L.hs_index_free.restype = None
+    L.hs_set_ef.argtypes = [vp, sz]
+    L.hs_index_info.argtypes = [vp, ctypes.POINTER(HsInfo)]
+    L.hs_set_capacity.argtypes = [vp, u32, u32]
+    L.hs_search_batch.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp]
+    L.hs_search_batch_dev.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
+    L.hs_search_check.argtypes = [vp, vp]
+    L.hs_search_batch_raw.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp]
+    L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
+    L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != HS_OK:
+        raise HsError(rc, lib().hs_last_error().decode())
+
+
+def device_count():
+    return lib().hs_device_count()
+
+
+def build_hnsw(base, out_path, metric=HS_METRIC_L2, M=16, ef_construction=200, branching_factor="4", seed=100, threads=1):
+    """HierarchicalNSW ctor + addPoint loop (labels = row index) + saveIndex, on the CPU (harness)."""
+    base = np.ascontiguousarray(base, np.float32)
+    _check(lib().hs_build_hnsw(base.ctypes.data, base.shape[0], base.shape[1], metric, M, ef_construction,
+                               str(branching_factor).encode(), seed, threads, out_path.encode()))
+
+
+def convert_slim(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=0, top_degree_percent0=0.02,
+                 top_degree_percent=0.02, top_degree_M0=32, low_degree_m0=8, top_degree_M=16, low_degree_m=4, threads=1):
+    """HierarchicalNSWSlim::convertFromHNSW + saveIndex, on the CPU (harness)."""
+    _check(lib().hs_convert_slim(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
+                                 top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
+
+
+class Index:
+    """A device-resident index (mirror of hnswlib::HierarchicalNSW / HierarchicalNSWSlim for search)."""
+
+    def __init__(self, path, kind, dim, metric=HS_METRIC_L2, max_elements=0, device=0):
+        self._h = ctypes.c_void_p()
+        self.kind, self.dim, self.metric, self.device = kind, dim, metric, device
+        self.ef = 10
+        _check(lib().hs_index_load(path.encode(), kind, metric, dim, max_elements, device, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().hs_index_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = HsInfo()
+        _check(lib().hs_index_info(self._h, ctypes.byref(i)))
+        return {f[0]: getattr(i, f[0]) for f in HsInfo._fields_}
+
+    def set_ef(self, ef):
+        self.ef = int(ef)
+        _check(lib().hs_set_ef(self._h, int(ef)))
+
+    def set_capacity(self, cand_cap=0, hash_slots=0):
+        _check(lib().hs_set_capacity(self._h, cand_cap, hash_slots))
+
+    # -- host-pointer API -------------------------------------------------------------------------
+    def search_ids(self, queries, k, want_dists=False, want_stats=False):
+        """HierarchicalNSWSlim::searchKnn(q, k, tableint*) for every row of `queries`."""
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        labels = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32) if want_dists else None
+        cnt = np.empty(nq, np.uint32)
+        stats = np.empty((nq, 4), np.uint32) if want_stats else None
+        _check(lib().hs_search_batch(self._h, q.ctypes.data, nq, k, HS_MODE_SLIM_IDS, labels.ctypes.data, None,
+                                     dists.ctypes.data if want_dists else None, cnt.ctypes.data,
+                                     stats.ctypes.data if want_stats else None))
+        return dict(labels=labels, dists=dists, cnt=cnt, stats=stats)
+
+    def search_pq(self, queries, k, want_stats=False):
+        """priority_queue-returning searchKnn overloads: the <=k (dist,label) pairs per query."""
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        labels = np.empty((nq, k), np.uint64)
+        dists = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        stats = np.empty((nq, 4), np.uint32) if want_stats else None
+        _check(lib().hs_search_batch(self._h, q.ctypes.data, nq, k, HS_MODE_PQ, None, labels.ctypes.data, dists.ctypes.data,
+                                     cnt.ctypes.data, stats.ctypes.data if want_stats else None))
+        return dict(labels=labels, dists=dists, cnt=cnt, stats=stats)
+
+    def search_raw(self, queries, k, mode=HS_MODE_SLIM_IDS):
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        cap = max(self.ef, k)
+        rd = np.empty((nq, cap), np.float32)
+        ri = np.empty((nq, cap), np.uint32)
+        rs = np.empty(nq, np.uint32)
+        stats = np.empty((nq, 4), np.uint32)
+        _check(lib().hs_search_batch_raw(self._h, q.ctypes.data, nq, k, mode, rd.ctypes.data, ri.ctypes.data, rs.ctypes.data,
+                                         stats.ctypes.data))
+        return dict(raw_d=rd, raw_i=ri, raw_sz=rs, stats=stats)
+
+    # -- device-pointer API (torch tensors on this index's device; async on `stream`) ----------------
+    def search_ids_dev(self, d_queries, k, d_labels, d_dists=None, d_counts=None, d_stats=None, stream=0):
+        nq = d_queries.shape[0]
+        _check(lib().hs_search_batch_dev(self._h, d_queries.data_ptr(), nq, k, HS_MODE_SLIM_IDS, d_labels.data_ptr(), None,
+                                         d_dists.data_ptr() if d_dists is not None else None,
+                                         d_counts.data_ptr() if d_counts is not None else None,
+                                         d_stats.data_ptr() if d_stats is not None else None, stream))
+
+    def check(self, stream=0):
+        _check(lib().hs_search_check(self._h, stream))

@@ -1,0 +1,362 @@
+// capi.cpp -- the C ABI (include/hnsw_slim_amd.h) over the HIP search engine.
+// Compiled by hipcc together with beam_search.hip into libhnsw_slim_amd.so.  No CPU search path
+// exists in this library: without a HIP device every search call returns HS_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/hnsw_slim_amd.h"
+#include "engine.hpp"
+#include "host_graph.hpp"
+
+using namespace hs;
+
+static thread_local std::string g_err;
+static hs_status fail(hs_status s, const std::string &msg) {
+  g_err = msg;
+  return s;
+}
+static hs_status from_exception(const std::exception &e) {
+  std::string m = e.what();
+  if (m == "Cannot open file") return fail(HS_ERR_IO, m);
+  if (m.find("corrupted") != std::string::npos) return fail(HS_ERR_CORRUPT, m);
+  if (m.find("Not enough memory") != std::string::npos) return fail(HS_ERR_NOMEM, m);
+  if (m.find("supports dim") != std::string::npos) return fail(HS_ERR_UNSUPPORTED, m);
+  return fail(HS_ERR_INVALID, m);
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return fail(HS_ERR_DEVICE, std::string(#expr ": ") + hipGetErrorString(_e)); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
+  hipError_t upload(const std::vector<T> &v) {
+    hipError_t e = alloc(std::max<size_t>(v.size(), 1));
+    if (e != hipSuccess) return e;
+    return v.empty() ? hipSuccess : hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct hs_index {
+  int device = 0;
+  hs_info info{};
+  size_t ef = 10;  // hnswalg.h:864, hnswalg_slim.h:793
+  uint32_t user_cand_cap = 0, user_hash_slots = 0;
+  DevIndex dev{};
+  DevBuf<float> vec;
+  DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr;
+  DevBuf<uint64_t> labels;
+  DevBuf<uint8_t> deleted;
+  // per-call workspace (grow-only)
+  DevBuf<uint32_t> status, counters;  // counters[0]: overflow after pass 1, [1]: after fallback
+  DevBuf<float> wq, wdist;
+  DevBuf<uint32_t> wl32, wcnt, wstats, wrawsz;
+  DevBuf<uint64_t> wl64;
+  DevBuf<Pair> wraw;
+};
+
+static uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+struct Shape {
+  uint32_t ef, cand_cap, hash_slots;
+  uint32_t fb_cand_cap, fb_hash_slots;  // fallback pass (one workgroup per CU, whole LDS)
+};
+static constexpr size_t kLdsPerCU = 160 * 1024;
+
+static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
+  const size_t ef = std::max(ix->ef, k);
+  if (ef > (1u << 20)) return fail(HS_ERR_INVALID, "ef too large");
+  s.ef = (uint32_t)ef;
+  s.cand_cap = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)(2 * ef + 256);
+  s.cand_cap = (s.cand_cap + 1) & ~1u;
+  s.hash_slots = ix->user_hash_slots ? next_pow2(ix->user_hash_slots) : next_pow2((uint32_t)(1.6 * (600 + 4 * ef)));
+  const uint32_t dim = (uint32_t)ix->info.dim;
+  // shrink the first-pass shape if it does not fit one CU at all
+  while (beam_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.hash_slots > 256) s.hash_slots >>= 1;
+  while (beam_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.cand_cap > 128) s.cand_cap = (s.cand_cap / 2 + 1) & ~1u;
+  if (beam_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU)
+    return fail(HS_ERR_CAPACITY, "ef/dim do not fit the 160 KiB LDS of one CU");
+  // fallback: the largest power-of-two hash that leaves at least as many bytes to the candidate heap
+  const size_t fixed = beam_lds_bytes(dim, s.ef, 0, 0);
+  size_t rem = kLdsPerCU - fixed;
+  uint32_t hs_slots = 256;
+  while ((size_t)hs_slots * 2 * 4 <= rem / 2) hs_slots *= 2;
+  s.fb_hash_slots = std::max(hs_slots, s.hash_slots);
+  size_t cand_bytes = kLdsPerCU - fixed - (size_t)s.fb_hash_slots * 4;
+  s.fb_cand_cap = (uint32_t)((cand_bytes / 8) & ~size_t(1));
+  if (s.fb_cand_cap < s.cand_cap) { s.fb_cand_cap = s.cand_cap; s.fb_hash_slots = s.hash_slots; }
+  return HS_OK;
+}
+
+extern "C" {
+
+const char *hs_last_error(void) { return g_err.c_str(); }
+
+int hs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static hs_status upload(hs_index *ix, const PackedIndex &p) {
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(ix->vec.upload(p.vec));
+  HIP_TRY(ix->row_ptr0.upload(p.row_ptr0));
+  HIP_TRY(ix->cols.upload(p.cols));
+  HIP_TRY(ix->up_base.upload(p.up_base));
+  HIP_TRY(ix->up_ptr.upload(p.up_ptr));
+  HIP_TRY(ix->labels.upload(p.labels));
+  HIP_TRY(ix->deleted.upload(p.deleted));
+  HIP_TRY(ix->counters.alloc(4));
+  DevIndex &d = ix->dev;
+  d.vec = ix->vec.p; d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p;
+  d.up_ptr = ix->up_ptr.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
+  d.n = (uint32_t)p.n; d.dim = (uint32_t)p.dim; d.maxlevel = p.maxlevel; d.threshold_level = p.threshold_level;
+  d.enterpoint = p.enterpoint; d.has_deleted = p.has_deleted; d.kind = p.kind; d.metric = p.metric;
+  hs_info &i = ix->info;
+  i.n = p.n; i.dim = p.dim; i.kind = p.kind; i.metric = p.metric; i.maxlevel = p.maxlevel;
+  i.threshold_level = p.threshold_level; i.enterpoint = p.enterpoint; i.has_deleted = p.has_deleted;
+  i.n_edges = p.cols.size(); i.max_degree0 = p.max_deg0;
+  i.device_bytes = p.vec.size() * 4 + (p.row_ptr0.size() + p.cols.size() + p.up_base.size() + p.up_ptr.size()) * 4 +
+                   p.labels.size() * 8 + p.deleted.size();
+  return HS_OK;
+}
+
+hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements, int device,
+                        hs_index **out) {
+  if (!path || !out) return fail(HS_ERR_INVALID, "null argument");
+  if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
+  if (dim == 0 || dim % 16 != 0)
+    return fail(HS_ERR_UNSUPPORTED, "dim % 16 != 0 is not supported yet (SIMD16 distance recipe only)");
+  if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
+  PackedIndex p;
+  try {
+    if (kind == HS_KIND_HNSW) {
+      VanillaGraph g;
+      g.load(path, (Metric)metric, dim, max_elements);
+      p.from_vanilla(g);
+    } else if (kind == HS_KIND_SLIM) {
+      SlimGraph g;
+      g.load(path, (Metric)metric, dim);
+      p.from_slim(g);
+    } else {
+      return fail(HS_ERR_INVALID, "bad index kind");
+    }
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory: loadIndex failed to allocate");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  hs_index *ix = new hs_index();
+  ix->device = device;
+  hs_status s = upload(ix, p);
+  if (s != HS_OK) { delete ix; return s; }
+  *out = ix;
+  return HS_OK;
+}
+
+void hs_index_free(hs_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  delete ix;
+}
+
+hs_status hs_set_ef(hs_index *ix, size_t ef) {
+  if (!ix) return fail(HS_ERR_INVALID, "null index");
+  ix->ef = ef;
+  return HS_OK;
+}
+hs_status hs_set_capacity(hs_index *ix, uint32_t cand_cap, uint32_t hash_slots) {
+  if (!ix) return fail(HS_ERR_INVALID, "null index");
+  ix->user_cand_cap = cand_cap;
+  ix->user_hash_slots = hash_slots;
+  return HS_OK;
+}
+hs_status hs_index_info(const hs_index *ix, hs_info *out) {
+  if (!ix || !out) return fail(HS_ERR_INVALID, "null argument");
+  *out = ix->info;
+  return HS_OK;
+}
+
+static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k, int mode, uint32_t *l32,
+                            uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, Pair *raw, uint32_t *rawsz,
+                            hipStream_t stream) {
+  if (!ix) return fail(HS_ERR_INVALID, "null index");
+  if (k == 0) return fail(HS_ERR_INVALID, "k must be > 0");
+  if (mode != HS_MODE_SLIM_IDS && mode != HS_MODE_PQ) return fail(HS_ERR_INVALID, "bad mode");
+  if (mode == HS_MODE_SLIM_IDS && ix->info.kind != HS_KIND_SLIM)
+    return fail(HS_ERR_INVALID, "HS_MODE_SLIM_IDS needs a Slim index (searchKnn(q,k,tableint*) exists on HierarchicalNSWSlim only)");
+  if (nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "nq too large");
+  if (nq == 0) return HS_OK;
+  Shape sh;
+  hs_status ps = plan_shape(ix, k, sh);
+  if (ps != HS_OK) return ps;
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(ix->status.ensure(nq));
+  HIP_TRY(hipMemsetAsync(ix->status.p, 0, nq * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(ix->counters.p, 0, 4 * sizeof(uint32_t), stream));
+  SearchArgs a{};
+  a.queries = d_q; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.ef = sh.ef;
+  a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.mode = mode;
+  a.mark_ep = (ix->info.kind == HS_KIND_SLIM && mode == HS_MODE_PQ) ? 1 : 0;
+  a.only_overflow = 0;
+  a.out_labels32 = l32; a.out_labels64 = l64; a.out_dists = dd; a.out_counts = cnt; a.stats = stats;
+  a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
+  a.status = ix->status.p; a.overflow_count = ix->counters.p;
+  HIP_TRY(launch_beam_search(ix->dev, a, stream));
+  if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
+    a.only_overflow = 1;
+    a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
+    a.overflow_count = ix->counters.p + 1;
+    HIP_TRY(launch_beam_search(ix->dev, a, stream));
+  }
+  return HS_OK;
+}
+
+hs_status hs_search_check(hs_index *ix, void *stream) {
+  if (!ix) return fail(HS_ERR_INVALID, "null index");
+  uint32_t c[4] = {0, 0, 0, 0};
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipMemcpyAsync(c, ix->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  // c[0] queries overflowed in pass 1; c[1] of those overflowed again in the fallback pass.
+  if (c[1] > 0 || (c[0] > 0 && false))
+    return fail(HS_ERR_CAPACITY, std::to_string(c[1]) + " queries exhausted the fallback on-chip scratch");
+  return HS_OK;
+}
+
+hs_status hs_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, size_t k, int mode,
+                              uint32_t *d_out_labels32, uint64_t *d_out_labels64, float *d_out_dists,
+                              uint32_t *d_out_counts, uint32_t *d_stats, void *stream) {
+  if (mode == HS_MODE_SLIM_IDS && !d_out_labels32) return fail(HS_ERR_INVALID, "out_labels32 required");
+  if (mode == HS_MODE_PQ && (!d_out_labels64 || !d_out_dists || !d_out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
+  return search_dev(ix, d_queries, nq, k, mode, d_out_labels32, d_out_labels64, d_out_dists, d_out_counts, d_stats,
+                    nullptr, nullptr, (hipStream_t)stream);
+}
+
+static hs_status search_host(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *l32,
+                             uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, float *raw_d, uint32_t *raw_i,
+                             uint32_t *raw_sz) {
+  if (!ix || !queries) return fail(HS_ERR_INVALID, "null argument");
+  if (nq == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t dim = ix->info.dim;
+  const size_t ef = std::max(ix->ef, k);
+  HIP_TRY(ix->wq.ensure(nq * dim));
+  HIP_TRY(ix->wl32.ensure(nq * k));
+  HIP_TRY(ix->wl64.ensure(nq * k));
+  HIP_TRY(ix->wdist.ensure(nq * k));
+  HIP_TRY(ix->wcnt.ensure(nq));
+  HIP_TRY(ix->wstats.ensure(nq * 4));
+  const bool want_raw = raw_d || raw_i || raw_sz;
+  if (want_raw) {
+    HIP_TRY(ix->wraw.ensure(nq * ef));
+    HIP_TRY(ix->wrawsz.ensure(nq));
+  }
+  hipStream_t st = nullptr;
+  HIP_TRY(hipMemcpyAsync(ix->wq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+  hs_status s = search_dev(ix, ix->wq.p, nq, k, mode, ix->wl32.p, ix->wl64.p, ix->wdist.p, ix->wcnt.p, ix->wstats.p,
+                           want_raw ? ix->wraw.p : nullptr, want_raw ? ix->wrawsz.p : nullptr, st);
+  if (s != HS_OK) return s;
+  s = hs_search_check(ix, st);
+  if (s != HS_OK) return s;
+  if (l32) HIP_TRY(hipMemcpy(l32, ix->wl32.p, nq * k * 4, hipMemcpyDeviceToHost));
+  if (l64) HIP_TRY(hipMemcpy(l64, ix->wl64.p, nq * k * 8, hipMemcpyDeviceToHost));
+  if (dd) HIP_TRY(hipMemcpy(dd, ix->wdist.p, nq * k * 4, hipMemcpyDeviceToHost));
+  if (cnt) HIP_TRY(hipMemcpy(cnt, ix->wcnt.p, nq * 4, hipMemcpyDeviceToHost));
+  if (stats) HIP_TRY(hipMemcpy(stats, ix->wstats.p, nq * 16, hipMemcpyDeviceToHost));
+  if (want_raw) {
+    std::vector<Pair> raw(nq * ef);
+    std::vector<uint32_t> sz(nq);
+    HIP_TRY(hipMemcpy(raw.data(), ix->wraw.p, nq * ef * sizeof(Pair), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sz.data(), ix->wrawsz.p, nq * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nq; i++) {
+      if (raw_sz) raw_sz[i] = sz[i];
+      for (size_t j = 0; j < ef; j++) {
+        const bool v = j < sz[i];
+        if (raw_d) raw_d[i * ef + j] = v ? raw[i * ef + j].d : 0.f;
+        if (raw_i) raw_i[i * ef + j] = v ? raw[i * ef + j].id : 0u;
+      }
+    }
+  }
+  return HS_OK;
+}
+
+hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *out_labels32,
+                          uint64_t *out_labels64, float *out_dists, uint32_t *out_counts, uint32_t *stats) {
+  if (mode == HS_MODE_SLIM_IDS && !out_labels32) return fail(HS_ERR_INVALID, "out_labels32 required");
+  if (mode == HS_MODE_PQ && (!out_labels64 || !out_dists || !out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
+  return search_host(ix, queries, nq, k, mode, out_labels32, out_labels64, out_dists, out_counts, stats, nullptr,
+                     nullptr, nullptr);
+}
+
+hs_status hs_search_batch_raw(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, float *raw_dists,
+                              uint32_t *raw_ids, uint32_t *raw_sizes, uint32_t *stats) {
+  if (!raw_dists || !raw_ids || !raw_sizes) return fail(HS_ERR_INVALID, "raw outputs required");
+  return search_host(ix, queries, nq, k, mode, nullptr, nullptr, nullptr, nullptr, stats, raw_dists, raw_ids, raw_sizes);
+}
+
+hs_status hs_build_hnsw(const float *base, size_t n, size_t dim, int metric, size_t M, size_t ef_construction,
+                        const char *branching_factor, size_t seed, int threads, const char *out_path) {
+  if (!base || !out_path || !branching_factor || n == 0) return fail(HS_ERR_INVALID, "bad argument");
+  try {
+    VanillaGraph g;
+    g.build(base, n, dim, (Metric)metric, M, ef_construction, branching_factor, seed, threads);
+    g.save(out_path);
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  return HS_OK;
+}
+
+hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int threshold_level, float top_degree_percent0,
+                          float top_degree_percent, size_t top_degree_M0, size_t low_degree_m0, size_t top_degree_M,
+                          size_t low_degree_m, int threads, const char *out_path) {
+  if (!hnsw_path || !out_path) return fail(HS_ERR_INVALID, "bad argument");
+  try {
+    VanillaGraph g;
+    g.load(hnsw_path, (Metric)metric, dim);
+    SlimParams p;
+    p.threshold_level = threshold_level;
+    p.top_pct0 = top_degree_percent0; p.top_pct = top_degree_percent;
+    p.top_M0 = top_degree_M0; p.low_m0 = low_degree_m0; p.top_M = top_degree_M; p.low_m = low_degree_m;
+    SlimGraph s;
+    s.convert(g, p, threads);
+    s.save(out_path);
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  return HS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// engine.hpp -- device-side index view + launch interface shared by beam_search.hip and capi.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "heap_emul.hpp"
+
+namespace hs {
+
+// Read-only index resident in HBM (one copy per GPU).
+struct DevIndex {
+  const float *vec;         // n x dim fp32, row-major, rows 64-byte aligned (dim % 16 == 0)
+  const uint32_t *row_ptr0; // n+1     : CSR row pointers of the level-0 adjacency
+  const uint32_t *cols;     // n_edges : neighbour ids (level 0 first, then upper-level slices)
+  const uint32_t *up_base;  // n       : first up_ptr entry of node i, 0xFFFFFFFF when level(i)==0
+  const uint32_t *up_ptr;   //         : level-l slice of i = cols[up_ptr[b+l-1] .. up_ptr[b+l])
+  const uint64_t *labels;   // n
+  const uint8_t *deleted;   // n       : delete mark as the reference reads it
+  uint32_t n, dim;
+  int32_t maxlevel, threshold_level;
+  uint32_t enterpoint;
+  int32_t has_deleted, kind, metric;
+};
+
+enum : uint32_t { ST_TODO = 0, ST_DONE = 1, ST_OVERFLOW = 2 };
+
+struct SearchArgs {
+  const float *queries;  // nq x dim (device)
+  uint32_t nq, k, ef;    // ef = max(ef_, k)   (hnswalg_slim.h:2080)
+  uint32_t cand_cap;     // candidate-heap capacity (entries)
+  uint32_t hash_slots;   // visited-set slots (power of two)
+  int32_t mode;          // hs_mode
+  int32_t mark_ep;       // tag the enter point visited before the descent (slim (q,k) overloads)
+  int32_t only_overflow; // fallback pass: only queries whose status == ST_OVERFLOW
+  uint32_t *out_labels32;
+  uint64_t *out_labels64;
+  float *out_dists;
+  uint32_t *out_counts;
+  uint32_t *stats;       // nq x 4 {n_dist, n_hops, n_nbr, fallback_used}   (nullable)
+  Pair *raw_top;         // nq x raw_stride (nullable)
+  uint32_t *raw_size;    // nq
+  uint32_t raw_stride;
+  uint32_t *status;      // nq
+  uint32_t *overflow_count;  // single counter: queries left in ST_OVERFLOW by this pass
+};
+
+// Bytes of dynamic LDS one query (one wavefront) needs for the given shape.
+size_t beam_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
+// Launch one wavefront per query on `stream`.
+hipError_t launch_beam_search(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+
+}  // namespace hs

@@ -1,0 +1,91 @@
+// selftest.cpp -- host-only check that heap_emul.hpp reproduces libstdc++'s heap / nth_element
+// mechanics bit for bit (array layout after every operation), on tie-heavy random sequences.
+// Exit code 0 = identical.  Run by tests/test_heap_emul.py.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <utility>
+#include <vector>
+
+#include "heap_emul.hpp"
+
+using P = std::pair<float, uint32_t>;
+struct LessP { bool operator()(const P &a, const P &b) const { return a.first < b.first; } };
+struct GreaterP { bool operator()(const P &a, const P &b) const { return a.first > b.first; } };
+
+static bool same(const std::vector<P> &s, const std::vector<hs::Pair> &e, size_t n) {
+  for (size_t i = 0; i < n; i++)
+    if (s[i].first != e[i].d || s[i].second != e[i].id) return false;
+  return true;
+}
+
+template <class SC, class EC>
+static int run_heap(unsigned seed, int range, SC sc, EC ec) {
+  std::mt19937 rng(seed);
+  std::vector<P> s;
+  std::vector<hs::Pair> e;
+  uint32_t next_id = 0;
+  for (int op = 0; op < 4000; op++) {
+    bool push = s.empty() || (rng() % 100) < 60;
+    if (push) {
+      float d = (float)(rng() % range);
+      s.emplace_back(d, next_id);
+      e.push_back({d, next_id});
+      next_id++;
+      std::push_heap(s.begin(), s.end(), sc);
+      hs::push_heap(e.data(), (long)e.size(), ec);
+    } else {
+      std::pop_heap(s.begin(), s.end(), sc);
+      hs::pop_heap(e.data(), (long)e.size(), ec);
+      if (!same(s, e, s.size())) return 1;
+      s.pop_back();
+      e.pop_back();
+    }
+    if (!same(s, e, s.size())) return 1;
+    if (op % 500 == 499) {  // make_heap on a shuffled copy
+      std::vector<P> s2 = s;
+      std::shuffle(s2.begin(), s2.end(), rng);
+      std::vector<hs::Pair> e2(s2.size());
+      for (size_t i = 0; i < s2.size(); i++) e2[i] = {s2[i].first, s2[i].second};
+      std::make_heap(s2.begin(), s2.end(), sc);
+      hs::make_heap(e2.data(), (long)e2.size(), ec);
+      if (!same(s2, e2, s2.size())) return 2;
+    }
+  }
+  return 0;
+}
+
+static int run_nth(unsigned seed, int range) {
+  std::mt19937 rng(seed);
+  for (int it = 0; it < 3000; it++) {
+    size_t n = 1 + rng() % 300;
+    size_t k = rng() % (n + 1);
+    std::vector<P> s(n);
+    std::vector<hs::Pair> e(n);
+    bool sorted_input = (it % 7 == 0), organ = (it % 11 == 0);
+    for (size_t i = 0; i < n; i++) {
+      float d = (float)(rng() % range);
+      if (sorted_input) d = (float)i;
+      if (organ) d = (float)(i < n / 2 ? i : n - i);
+      s[i] = {d, (uint32_t)i};
+      e[i] = {d, (uint32_t)i};
+    }
+    std::nth_element(s.begin(), s.begin() + k, s.end(), LessP());
+    hs::nth_element(e.data(), (long)k, (long)n, hs::LessD());
+    if (!same(s, e, n)) return 3;
+  }
+  return 0;
+}
+
+int main() {
+  int rc = 0;
+  for (unsigned seed = 1; seed <= 8 && !rc; seed++)
+    for (int range : {3, 17, 1000, 1 << 20}) {
+      if ((rc = run_heap(seed, range, LessP(), hs::LessD()))) break;
+      if ((rc = run_heap(seed + 100, range, GreaterP(), hs::GreaterD()))) break;
+      if ((rc = run_nth(seed + 200, range))) break;
+    }
+  printf(rc ? "heap_emul MISMATCH rc=%d\n" : "heap_emul identical to libstdc++ (rc=%d)\n", rc);
+  return rc;
+}

@@ -1,0 +1,118 @@
+/* hnsw_slim_amd.h -- C ABI of the MI355X-native HNSW / HNSW-Slim batched search engine.
+ *
+ * This is the drop-in boundary for the reference's searchKnn -> searchBaseLayerST -> distance path
+ * (SURVEY.md section 8b).  Plain pointers and sizes only; every entry point names the reference
+ * interface it replaces (paths relative to /root/reference/third_party/hnswlib/).  The C++ facade
+ * hnsw-slim_amd/hnswlib/hnswlib_amd.h re-creates hnswlib::HierarchicalNSW / HierarchicalNSWSlim /
+ * L2Space / InnerProductSpace on top of these calls.
+ *
+ * Error convention: every call returns an hs_status; hs_last_error() gives the thread-local message,
+ * which reuses the reference's exception texts ("Cannot open file", "Index seems to be corrupted or
+ * unsupported", ...) so the facade can re-throw std::runtime_error with the same what().
+ * There is NO CPU fallback: without a HIP device every search entry point fails with HS_ERR_DEVICE.
+ */
+#ifndef HNSW_SLIM_AMD_H
+#define HNSW_SLIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hs_index hs_index;
+
+typedef enum {
+  HS_OK = 0,
+  HS_ERR_IO = 1,          /* "Cannot open file"                         hnswalg.h:785, hnswalg_slim.h:757 */
+  HS_ERR_CORRUPT = 2,     /* "Index seems to be corrupted or unsupported" hnswalg.h:823-836 */
+  HS_ERR_NOMEM = 3,       /* "Not enough memory: ..."                   hnswalg_slim.h:785-788 */
+  HS_ERR_INVALID = 4,     /* bad argument                                */
+  HS_ERR_UNSUPPORTED = 5, /* e.g. dim % 16 != 0 this round               */
+  HS_ERR_DEVICE = 6,      /* HIP runtime error / no device               */
+  HS_ERR_CAPACITY = 7     /* a query outgrew even the fallback on-chip scratch */
+} hs_status;
+
+typedef enum { HS_KIND_HNSW = 0, HS_KIND_SLIM = 1 } hs_kind;   /* hnswalg.h:18 / hnswalg_slim.h:29 */
+typedef enum { HS_METRIC_L2 = 0, HS_METRIC_IP = 1 } hs_metric; /* space_l2.h:208 / space_ip.h:342  */
+
+/* Which searchKnn overload a batch call reproduces. */
+typedef enum {
+  /* HierarchicalNSWSlim::searchKnn(const void*, size_t k, tableint* result)  hnswalg_slim.h:2030-2131:
+   * k uint32 labels per query in the reference's post-nth_element array order. */
+  HS_MODE_SLIM_IDS = 0,
+  /* priority_queue-returning overloads: HierarchicalNSW::searchKnn hnswalg.h:1378-1440 and
+   * HierarchicalNSWSlim::searchKnn(q,k) hnswalg_slim.h:1907-2028: <=k (dist,label) pairs per query. */
+  HS_MODE_PQ = 1
+} hs_mode;
+
+typedef struct {
+  uint64_t n, dim;
+  int32_t kind, metric, maxlevel, threshold_level;
+  uint32_t enterpoint;
+  int32_t has_deleted;
+  uint64_t n_edges;      /* entries of the CSR column array (all levels) */
+  uint64_t device_bytes; /* HBM held by this index */
+  uint64_t max_degree0;
+} hs_info;
+
+const char *hs_last_error(void);
+
+/* Number of HIP devices visible (0 when none); does not initialise a device context. */
+int hs_device_count(void);
+
+/* loadIndex(path, space, max_elements): hnswalg.h:781-893 (HS_KIND_HNSW), hnswalg_slim.h:753-815
+ * (HS_KIND_SLIM).  Parses the reference's serialized index, repacks it (row-major vectors + CSR
+ * adjacency) and uploads it to HIP device `device`.  ef starts at 10 as in the reference. */
+hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements,
+                        int device, hs_index **out);
+void hs_index_free(hs_index *ix);                        /* ~HierarchicalNSW* / clear(): hnswalg_slim.h:154-167 */
+hs_status hs_set_ef(hs_index *ix, size_t ef);            /* setEf: hnswalg.h:184, hnswalg_slim.h:193 */
+hs_status hs_index_info(const hs_index *ix, hs_info *out);
+
+/* On-chip scratch sizing per query (0 = automatic from ef): candidate-heap capacity and visited-set
+ * hash slots (power of two).  Queries that outgrow it are re-run with a whole CU's LDS. */
+hs_status hs_set_capacity(hs_index *ix, uint32_t cand_cap, uint32_t hash_slots);
+
+/* Batched searchKnn over nq host-resident queries (nq x dim, row-major fp32).  Outputs (host):
+ *   mode HS_MODE_SLIM_IDS: out_labels32[nq*k] (required); out_dists[nq*k] (nullable) in the same order.
+ *   mode HS_MODE_PQ      : out_labels64[nq*k] + out_dists[nq*k] (required): the pairs left in
+ *                          top_candidates after popping down to k, heap-array order; out_counts[nq].
+ *   out_counts[nq] (nullable): number of valid entries per query (min(k, found)); unused slots hold
+ *                          0xFFFFFFFF / UINT64_MAX / +inf.
+ *   stats (nullable): nq x 4 uint32 {n_dist, n_hops, n_nbr_read, fallback_used}  (SURVEY.md 8d).
+ * Synchronous: includes H2D of queries and D2H of results. */
+hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, int mode,
+                          uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists,
+                          uint32_t *out_counts, uint32_t *stats);
+
+/* Same search with DEVICE pointers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ * No host synchronisation happens here; call hs_search_check() after synchronising to learn whether
+ * any query exhausted the fallback scratch. */
+hs_status hs_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, size_t k, int mode,
+                              uint32_t *d_out_labels32, uint64_t *d_out_labels64, float *d_out_dists,
+                              uint32_t *d_out_counts, uint32_t *d_stats, void *stream);
+hs_status hs_search_check(hs_index *ix, void *stream);
+
+/* Parity/debug entry: raw top_candidates arrays after the level-0 beam, exactly as the reference holds
+ * them before selection (hnswalg_slim.h:2116-2124): raw_dists/raw_ids are nq x max(ef,k), raw_sizes nq.
+ * mark_ep_visited selects the (q,k)/(q,k,filter) overloads' extra visited tag (hnswalg_slim.h:1796,1919). */
+hs_status hs_search_batch_raw(hs_index *ix, const float *queries, size_t nq, size_t k, int mode,
+                              float *raw_dists, uint32_t *raw_ids, uint32_t *raw_sizes, uint32_t *stats);
+
+/* ---- harness (CPU, not accelerated): produce index files in the reference's formats ------------ */
+/* HierarchicalNSW ctor + addPoint loop + saveIndex: hnswalg.h:85-159, 1248-1376, 748-779.
+ * labels = row index; threads==1 reproduces the reference's serial build byte for byte. */
+hs_status hs_build_hnsw(const float *base, size_t n, size_t dim, int metric, size_t M, size_t ef_construction,
+                        const char *branching_factor, size_t seed, int threads, const char *out_path);
+/* HierarchicalNSWSlim::convertFromHNSW + saveIndex: hnswalg_slim.h:867-1108, 717-751. */
+hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int threshold_level,
+                          float top_degree_percent0, float top_degree_percent, size_t top_degree_M0,
+                          size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int threads,
+                          const char *out_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSW_SLIM_AMD_H */

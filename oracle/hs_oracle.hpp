@@ -321,8 +321,8 @@ inline void beam_level0(const Index &ix, const float *q, size_t ef, bool bare_bo
     s.cand.pop_back();
     const uint32_t *ids;
     size_t n;
-    if (!list0(cur.second, ids, n)) continue;                      // :360-362
     c.n_hops++;
+    if (!list0(cur.second, ids, n)) continue;                      // :360-362
     if (n == 0) continue;                                          // :366-367
     for (size_t j = 0; j < n; j++) {                               // :383
       uint32_t id = ids[j];
@@ -363,8 +363,8 @@ inline void slim_upper(const SlimIndex &ix, const float *q, uint32_t &cur, float
       changed = false;
       const uint32_t *ids;
       size_t n;
-      if (!ix.slice(cur, lvl, ids, n)) continue;   // :2047-2049
       c.n_hops++;
+      if (!ix.slice(cur, lvl, ids, n)) continue;   // :2047-2049
       if (n == 0) continue;                          // :2057-2058
       for (size_t i = 0; i < n; i++) {               // scan continues over the OLD node's list
         uint32_t cand = ids[i];
@@ -389,8 +389,8 @@ inline void slim_beam_layer(const SlimIndex &ix, const float *q, int layer, size
     s.cand.pop_back();
     const uint32_t *ids;
     size_t n;
-    if (!ix.slice(cur.second, layer, ids, n)) continue;
     c.n_hops++;
+    if (!ix.slice(cur.second, layer, ids, n)) continue;
     if (n == 0) continue;
     for (size_t j = 0; j < n; j++) {
       uint32_t id = ids[j];

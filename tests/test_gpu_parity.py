@@ -1,0 +1,151 @@
+"""GPU parity tests (MI355X): the HIP search path, called through the C ABI, against
+  (a) the compiled reference's own outputs (tests/golden, vanilla HNSW), and
+  (b) the CPU oracle (oracle/) on the same index file and queries.
+Bar: neighbour ids / labels bit-exact (including the reference's output order where it defines one),
+fp32 distances bit-exact (the north star allows 1e-4 relative; we hold the stricter bar), counters equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from hsutil import GOLDEN, load_product, mixture
+
+pytestmark = pytest.mark.gpu
+L2, IP = 0, 1
+
+
+@pytest.fixture(scope="module")
+def hs():
+    m = load_product()
+    assert os.path.exists(m.LIB_PATH), "HIP extension missing: run __graft_entry__.build()"
+    assert m.device_count() > 0, "no HIP device visible"
+    return m
+
+
+def _pq_sorted(d, l, c):
+    """(dist,label) multiset per query, sorted, as comparable arrays."""
+    out = []
+    for i in range(len(c)):
+        n = int(c[i])
+        rec = sorted(zip(d[i, :n].view(np.uint32).tolist(), l[i, :n].tolist()))
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48)])
+def test_vanilla_vs_compiled_reference(hs, oracle, name, metric, dim):
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    path = os.path.join(GOLDEN, f"{name}.hnsw.bin")
+    ix = hs.Index(path, hs.HS_KIND_HNSW, dim, metric)
+    ox = oracle.load(path, "hnsw", metric, dim)
+    k = int(g["k"])
+    for ef in g["efs"]:
+        ef = int(ef)
+        ix.set_ef(ef)
+        ox.set_ef(ef)
+        r = ix.search_pq(g["queries"], k, want_stats=True)
+        assert np.array_equal(r["cnt"], g[f"ef{ef}_cnt"])
+        assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(g[f"ef{ef}_dists"], g[f"ef{ef}_labels"], g[f"ef{ef}_cnt"]), f"{name} ef={ef}"
+        assert np.array_equal(r["stats"][:, 0], g[f"ef{ef}_calls"]), "distance-evaluation count differs from the reference"
+        # raw heap arrays: identical layout to the oracle's libstdc++ heaps
+        raw = ix.search_raw(g["queries"], k, mode=hs.HS_MODE_PQ)
+        o = ox.search_pq(g["queries"], k)
+        assert np.array_equal(raw["raw_sz"], o["raw_sz"])
+        for i in range(len(raw["raw_sz"])):
+            n = int(raw["raw_sz"][i])
+            assert np.array_equal(raw["raw_i"][i, :n], o["raw_i"][i, :n])
+            assert raw["raw_d"][i, :n].tobytes() == o["raw_d"][i, :n].tobytes()
+        assert np.array_equal(raw["stats"][:, :3], o["counters"][:, :3])
+
+
+def _slim_case(hs, oracle, tmp_path, base, queries, dim, metric, M, efC, efs, k=10, threads=8, **slim_kw):
+    hp, sp = str(tmp_path / "h.bin"), str(tmp_path / "s.bin")
+    hs.build_hnsw(base, hp, metric=metric, M=M, ef_construction=efC, threads=threads)
+    hs.convert_slim(hp, sp, dim, metric=metric, threads=threads, **slim_kw)
+    ix = hs.Index(sp, hs.HS_KIND_SLIM, dim, metric)
+    ox = oracle.load(sp, "slim", metric, dim)
+    for ef in efs:
+        ix.set_ef(ef)
+        ox.set_ef(ef)
+        o = ox.search_ids(queries, k, threads=8)
+        r = ix.search_ids(queries, k, want_dists=True, want_stats=True)
+        assert np.array_equal(r["labels"], o["labels"]), f"ef={ef}: labels differ from searchKnn(q,k,tableint*)"
+        assert np.array_equal(r["stats"][:, :3], o["counters"][:, :3]), f"ef={ef}: counters differ"
+        raw = ix.search_raw(queries, k)
+        assert np.array_equal(raw["raw_sz"], o["raw_sz"])
+        cap = max(ef, k)
+        mask = np.arange(cap)[None, :] < raw["raw_sz"][:, None]
+        assert np.array_equal(raw["raw_i"][mask], o["raw_i"][mask])
+        assert raw["raw_d"][mask].tobytes() == o["raw_d"][mask].tobytes()
+        # priority_queue overload (marks the enter point visited first)
+        op = ox.search_pq(queries, k, threads=8)
+        rp = ix.search_pq(queries, k)
+        assert np.array_equal(rp["cnt"], op["cnt"])
+        assert _pq_sorted(rp["dists"], rp["labels"], rp["cnt"]) == _pq_sorted(op["dists"], op["labels"], op["cnt"])
+    return ix, ox
+
+
+def test_slim_from_golden_index(hs, oracle, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "l2_int_d16.npz"))
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(os.path.join(GOLDEN, "l2_int_d16.hnsw.bin"), sp, 16)
+    ix = hs.Index(sp, hs.HS_KIND_SLIM, 16)
+    ox = oracle.load(sp, "slim", L2, 16)
+    for ef in (10, 32, 64, 200):
+        ix.set_ef(ef)
+        ox.set_ef(ef)
+        assert np.array_equal(ix.search_ids(g["queries"], 10)["labels"], ox.search_ids(g["queries"], 10)["labels"])
+
+
+def test_slim_sift_like_d128(hs, oracle, tmp_path):
+    base = mixture(20000, 128, 21, n_clusters=64, integer=True)
+    q = mixture(400, 128, 22, n_clusters=64, integer=True)
+    _slim_case(hs, oracle, tmp_path, base, q, 128, L2, 16, 200, [32, 64, 128, 256])
+
+
+def test_slim_continuous_d96(hs, oracle, tmp_path):
+    base = mixture(8000, 96, 23, lo=-1, hi=1, sigma=0.3)
+    q = mixture(200, 96, 24, lo=-1, hi=1, sigma=0.3)
+    _slim_case(hs, oracle, tmp_path, base, q, 96, L2, 16, 100, [16, 64])
+
+
+def test_slim_gist_like_d960(hs, oracle, tmp_path):
+    base = np.clip(mixture(3000, 960, 25, lo=0.2, hi=0.8, sigma=0.08), 0, 1)
+    q = np.clip(mixture(64, 960, 26, lo=0.2, hi=0.8, sigma=0.08), 0, 1)
+    _slim_case(hs, oracle, tmp_path, base, q, 960, L2, 16, 100, [64])
+
+
+def test_slim_ip_d768(hs, oracle, tmp_path):
+    base = mixture(3000, 768, 27, lo=-1, hi=1, sigma=0.5)
+    q = mixture(64, 768, 28, lo=-1, hi=1, sigma=0.5)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _slim_case(hs, oracle, tmp_path, base.astype(np.float32), q.astype(np.float32), 768, IP, 16, 100, [64])
+
+
+def test_slim_threshold_level(hs, oracle, tmp_path):
+    base = mixture(6000, 32, 29)
+    q = mixture(200, 32, 30)
+    _slim_case(hs, oracle, tmp_path, base, q, 32, L2, 8, 100, [16, 64], threshold_level=1)
+
+
+def test_fallback_pass_is_exact(hs, oracle, tmp_path):
+    """Starve the first-pass scratch so queries overflow into the whole-CU fallback: same answers."""
+    base = mixture(6000, 32, 31)
+    q = mixture(128, 32, 32)
+    ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 32, L2, 8, 100, [64])
+    ix.set_ef(64)
+    ox.set_ef(64)
+    ix.set_capacity(cand_cap=80, hash_slots=256)
+    r = ix.search_ids(q, 10, want_stats=True)
+    assert r["stats"][:, 3].sum() > 0, "expected some queries to take the fallback pass"
+    assert np.array_equal(r["labels"], ox.search_ids(q, 10)["labels"])
+    ix.set_capacity(0, 0)
+
+
+def test_k_larger_than_ef_and_k_equals_n(hs, oracle, tmp_path):
+    base = mixture(500, 16, 33)
+    q = mixture(20, 16, 34)
+    ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 16, L2, 8, 50, [4], k=20)  # ef = max(ef_, k)
+    assert ix.info()["n"] == 500

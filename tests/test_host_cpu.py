@@ -1,0 +1,116 @@
+"""CPU-only tests of the product's host side: C-ABI exports, heap/selection emulation vs libstdc++,
+the HNSW builder vs the compiled reference's index file, Slim conversion + file round trip, errors."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from hsutil import GOLDEN, ROOT, load_product, mixture
+
+L2, IP = 0, 1
+
+
+@pytest.fixture(scope="module")
+def hs():
+    m = load_product()
+    m.build_library()
+    return m
+
+
+def test_c_abi_exports_every_declared_symbol(hs):
+    hdr = open(os.path.join(ROOT, "include", "hnsw_slim_amd.h")).read()
+    declared = set(re.findall(r"\b(hs_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"hs_status"}
+    L = hs.lib()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/hnsw_slim_amd.h but not exported"
+    assert set(hs.EXPORTS) <= declared
+
+
+def test_heap_emulation_matches_libstdcxx(hs):
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "selftest")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "selftest"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("name,metric", [("l2_cont_d32", L2), ("l2_int_d16", L2), ("ip_d48", IP)])
+def test_serial_builder_writes_reference_bytes(hs, tmp_path, name, metric):
+    """threads=1 build == the reference's serial addPoint loop + saveIndex, byte for byte."""
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    out = str(tmp_path / "mine.bin")
+    hs.build_hnsw(g["base"], out, metric=metric, M=int(g["M"]), ef_construction=int(g["efC"]), branching_factor="4", seed=100, threads=1)
+    ref = open(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "rb").read()
+    assert open(out, "rb").read() == ref
+
+
+def test_parallel_builder_is_searchable(hs, oracle, tmp_path):
+    base = mixture(3000, 32, 11)
+    q = mixture(50, 32, 12)
+    out = str(tmp_path / "par.bin")
+    hs.build_hnsw(base, out, M=8, ef_construction=100, threads=4)
+    ix = oracle.load(out, "hnsw", L2, 32)
+    ix.set_ef(64)
+    r = ix.search_pq(q, 10)
+    gt = oracle.brute_force(L2, base, q, 10)
+    # pop order is farthest-first; compare as sets
+    hits = sum(len(set(map(int, r["labels"][i])) & set(map(int, gt[i]))) for i in range(len(q)))
+    assert hits / (10 * len(q)) > 0.9
+
+
+def test_slim_convert_roundtrip(hs, oracle, tmp_path):
+    """convertFromHNSW -> saveIndex -> (oracle) loadIndex: structure invariants of the CHAL blobs."""
+    src = os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin")
+    out = str(tmp_path / "slim.bin")
+    hs.convert_slim(src, out, 32)
+    data = open(out, "rb").read()
+    n = int(np.frombuffer(data, np.uint64, 1, 0)[0])
+    spe = int(np.frombuffer(data, np.uint64, 1, 8)[0])
+    assert n == 2000 and spe == 24 + 4 * 32
+    # independent parse of the documented layout ('<6Q2iI4Q?' = 93-byte header)
+    off = 93
+    el = np.frombuffer(data, np.uint8, n * spe, off).reshape(n, spe)
+    level = el[:, 0:4].copy().view(np.int32)[:, 0]
+    total = el[:, 4:8].copy().view(np.uint32)[:, 0]
+    off += n * spe
+    for i in range(n):
+        sz = int(np.frombuffer(data, np.uint32, 1, off)[0]); off += 4
+        assert sz == 2 * level[i] + 4 * total[i]
+        if sz and total[i]:
+            offs = np.frombuffer(data, np.uint16, level[i], off)
+            ids = np.frombuffer(data, np.uint32, total[i], off + 2 * level[i])
+            assert np.all(np.diff(np.concatenate([[0], offs, [total[i]]]).astype(np.int64)) >= 0)
+            assert ids.max() < n
+            lvl0 = ids[: (offs[0] if level[i] else total[i])]
+            assert len(lvl0) <= 16 and len(set(lvl0.tolist())) == len(lvl0)  # unique; id-sorted unless re-pruned (slim.h:1005-1010, 1038-1062)
+            off += sz
+    assert off == len(data)
+    # vectors and labels carried over unchanged
+    g = np.load(os.path.join(GOLDEN, "l2_cont_d32.npz"))
+    assert np.array_equal(el[:, 24:].copy().view(np.float32), g["base"])
+    # and the oracle can search it
+    ix = oracle.load(out, "slim", L2, 32)
+    ix.set_ef(64)
+    r = ix.search_ids(g["queries"], 10)
+    gt = oracle.brute_force(L2, g["base"], g["queries"], 10)
+    hits = sum(len(set(map(int, r["labels"][i])) & set(map(int, gt[i]))) for i in range(len(gt)))
+    assert hits / gt.size > 0.8
+
+
+def test_error_conventions(hs, tmp_path):
+    with pytest.raises(hs.HsError, match="dim % 16"):
+        hs.Index(str(tmp_path / "x"), hs.HS_KIND_SLIM, 30)
+    if hs.device_count() == 0:
+        with pytest.raises(hs.HsError) as e:
+            hs.Index(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), hs.HS_KIND_HNSW, 32)
+        assert e.value.status == hs.HS_ERR_DEVICE  # no CPU fallback: fails loudly
+    with pytest.raises(hs.HsError, match="Cannot open file"):
+        hs.convert_slim(str(tmp_path / "nope.bin"), str(tmp_path / "o.bin"), 32)
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(open(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), "rb").read()[:5000])
+    with pytest.raises(hs.HsError, match="corrupted"):
+        hs.convert_slim(str(bad), str(tmp_path / "o.bin"), 32)
