@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhnsw_slim_amd.so")
+LIB_PATH = os.environ.get("HS_LIB", os.path.join(_HERE, "libhnsw_slim_amd.so"))  # HS_LIB: diagnostic builds only
 
 HS_KIND_HNSW, HS_KIND_SLIM = 0, 1
 HS_METRIC_L2, HS_METRIC_IP = 0, 1

@@ -122,7 +122,19 @@ struct QState {
   uint32_t top_size, cand_size, n_ins;
   float lb;
   uint32_t n_dist, n_hops, n_nbr;
+#ifdef HS_PROFILE
+  unsigned long long t[8];  // cycles: 0 pop, 1 adjacency, 2 visited, 3 distances, 4 accept, 5 upper, 6 init, 7 final
+#endif
 };
+// Diagnostic build only (make prof): per-phase shader-clock stamps, written to the stats buffer's
+// tail; the product build compiles these to nothing.
+#ifdef HS_PROFILE
+#define HS_T0() unsigned long long _t0 = clock64()
+#define HS_LAP(st, i) do { unsigned long long _t1 = clock64(); (st).t[i] += _t1 - _t0; _t0 = _t1; } while (0)
+#else
+#define HS_T0() do {} while (0)
+#define HS_LAP(st, i) do {} while (0)
+#endif
 
 // One best-first beam over the `level` slices (level 0: searchBaseLayerST; >0: searchBaseLayer).
 // Returns false when the on-chip scratch overflowed.
@@ -132,6 +144,7 @@ __device__ bool beam(const DevIndex &ix, const SearchArgs &a, int level, bool ba
   const uint32_t ef = a.ef;
   const uint32_t hmask = a.hash_slots - 1;
   const uint32_t hash_limit = a.hash_slots - (a.hash_slots >> 2);
+  HS_T0();
   while (true) {
     wave_sync();
     if (st.cand_size == 0) break;
@@ -144,6 +157,8 @@ __device__ bool beam(const DevIndex &ix, const SearchArgs &a, int level, bool ba
     if (lane == 0) pop_heap(cand, (long)st.cand_size, GreaterD());  // :353-354
     st.cand_size--;
     st.n_hops++;
+    wave_sync();
+    HS_LAP(st, 0);
     uint32_t s, e;
     if (level == 0) {
       s = ix.row_ptr0[cid];
@@ -161,10 +176,12 @@ __device__ bool beam(const DevIndex &ix, const SearchArgs &a, int level, bool ba
       if (st.n_ins + m > hash_limit || st.cand_size + m > a.cand_cap) return false;
       uint32_t id = 0;
       bool isnew = false;
-      if ((uint32_t)lane < m) {
-        id = ix.cols[base + lane];
-        isnew = hash_insert(hash, hmask, id);  // :392-393
-      }
+      if ((uint32_t)lane < m) id = ix.cols[base + lane];
+#ifdef HS_PROFILE
+      id = __shfl(id, lane, 64);  // force the load to land before the stamp
+#endif
+      HS_LAP(st, 1);
+      if ((uint32_t)lane < m) isnew = hash_insert(hash, hmask, id);  // :392-393
       const unsigned long long nm = __ballot(isnew);
       const uint32_t cnt = __popcll(nm);
       st.n_nbr += m;
@@ -174,8 +191,10 @@ __device__ bool beam(const DevIndex &ix, const SearchArgs &a, int level, bool ba
       wave_sync();
       st.n_ins += cnt;
       st.n_dist += cnt;
+      HS_LAP(st, 2);
       wave_dists<METRIC>(ix, qv, nid, nd, cnt, lane);  // :395-396
       wave_sync();
+      HS_LAP(st, 3);
       uint32_t ts = st.top_size, cs = st.cand_size;
       float lb = st.lb;
       if (lane == 0) {
@@ -204,6 +223,7 @@ __device__ bool beam(const DevIndex &ix, const SearchArgs &a, int level, bool ba
       st.top_size = uni(ts);
       st.cand_size = uni(cs);
       st.lb = unif(lb);
+      HS_LAP(st, 4);
     }
   }
   return true;
@@ -234,6 +254,10 @@ __device__ void search_one(const DevIndex &ix, const SearchArgs &a, const uint32
   for (uint32_t i = lane; i < ix.dim; i += 64) qv[i] = a.queries[(size_t)qi * ix.dim + i];
   for (uint32_t i = lane; i < a.hash_slots; i += 64) hash[i] = kEmpty;
   QState st;
+#ifdef HS_PROFILE
+  for (int i = 0; i < 8; i++) st.t[i] = 0;
+#endif
+  HS_T0();
   st.n_dist = st.n_hops = st.n_nbr = 0;
   st.n_ins = 0;
   st.top_size = st.cand_size = 0;
@@ -251,6 +275,7 @@ __device__ void search_one(const DevIndex &ix, const SearchArgs &a, const uint32
     st.n_ins++;
   }
 
+  HS_LAP(st, 6);
   // ---- upper layers: greedy descent (hnswalg_slim.h:2040-2078, hnswalg.h:1389-1415) ------------
   for (int lvl = ix.maxlevel; lvl > ix.threshold_level; lvl--) {
     bool changed = true;
@@ -287,6 +312,7 @@ __device__ void search_one(const DevIndex &ix, const SearchArgs &a, const uint32
     }
   }
 
+  HS_LAP(st, 5);
   // ---- level-0 (and threshold-level) beams ----------------------------------------------------
   bool bare = !ix.has_deleted;  // hnswalg_slim.h:2114, hnswalg.h:1421 (no filter on this path)
   const bool ep_deleted = ix.deleted[cur] != 0;
@@ -334,6 +360,9 @@ __device__ void search_one(const DevIndex &ix, const SearchArgs &a, const uint32
   }
 
   // ---- raw result heap (parity/debug) ---------------------------------------------------------
+#ifdef HS_PROFILE
+  _t0 = clock64();
+#endif
   if (a.raw_top) {
     for (uint32_t i = lane; i < st.top_size; i += 64) a.raw_top[(size_t)qi * a.raw_stride + i] = top[i];
     if (lane == 0) a.raw_size[qi] = st.top_size;
@@ -369,6 +398,12 @@ __device__ void search_one(const DevIndex &ix, const SearchArgs &a, const uint32
       a.stats[qi * 4 + 1] = st.n_hops;
       a.stats[qi * 4 + 2] = st.n_nbr;
       a.stats[qi * 4 + 3] = a.only_overflow ? 1u : 0u;
+#ifdef HS_PROFILE
+      HS_LAP(st, 7);
+      // diagnostic build: phase cycles go to a buffer of their own behind the nq x 4 stats block
+      unsigned long long *pt = reinterpret_cast<unsigned long long *>(a.stats + (size_t)a.nq * 4) + (size_t)qi * 8;
+      for (int i = 0; i < 8; i++) pt[i] = st.t[i];
+#endif
     }
     a.status[qi] = ST_DONE;
   }
