@@ -21,7 +21,7 @@ HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORT
 
 EXPORTS = [
     "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
-    "hs_set_capacity", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw",
+    "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw",
     "hs_build_hnsw", "hs_convert_slim",
 ]
 
@@ -66,6 +66,7 @@ def lib():
     L.hs_set_ef.argtypes = [vp, sz]
     L.hs_index_info.argtypes = [vp, ctypes.POINTER(HsInfo)]
     L.hs_set_capacity.argtypes = [vp, u32, u32]
+    L.hs_set_exact_order.argtypes = [vp, ci]
     L.hs_search_batch.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp]
     L.hs_search_batch_dev.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_search_check.argtypes = [vp, vp]
@@ -127,6 +128,10 @@ class Index:
     def set_ef(self, ef):
         self.ef = int(ef)
         _check(lib().hs_set_ef(self._h, int(ef)))
+
+    def set_exact_order(self, on=True):
+        """True: strict kernel for every query (reference array order); False: fast kernel, sorted output."""
+        _check(lib().hs_set_exact_order(self._h, 1 if on else 0))
 
     def set_capacity(self, cand_cap=0, hash_slots=0):
         _check(lib().hs_set_capacity(self._h, cand_cap, hash_slots))

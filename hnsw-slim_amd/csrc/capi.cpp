@@ -64,13 +64,16 @@ struct hs_index {
   hs_info info{};
   size_t ef = 10;  // hnswalg.h:864, hnswalg_slim.h:793
   uint32_t user_cand_cap = 0, user_hash_slots = 0;
+  uint32_t grow_cand = 0, grow_hash = 0;  // adaptive: doublings learnt from earlier batches' overflow counts
+  bool exact_order = false;               // always use the strict kernel (reference output order)
+  size_t last_nq = 0;
   DevIndex dev{};
   DevBuf<float> vec;
-  DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr;
+  DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr, tile0;
   DevBuf<uint64_t> labels;
   DevBuf<uint8_t> deleted;
   // per-call workspace (grow-only)
-  DevBuf<uint32_t> status, counters;  // counters[0]: overflow after pass 1, [1]: after fallback
+  DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, -}
   DevBuf<float> wq, wdist;
   DevBuf<uint32_t> wl32, wcnt, wstats, wrawsz;
   DevBuf<uint64_t> wl64;
@@ -85,7 +88,7 @@ static uint32_t next_pow2(uint32_t v) {
 
 struct Shape {
   uint32_t ef, cand_cap, hash_slots;
-  uint32_t fb_cand_cap, fb_hash_slots;  // fallback pass (one workgroup per CU, whole LDS)
+  uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
 
@@ -93,17 +96,18 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
   if (ef > (1u << 20)) return fail(HS_ERR_INVALID, "ef too large");
   s.ef = (uint32_t)ef;
-  s.cand_cap = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)(2 * ef + 256);
+  s.cand_cap = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((3 * ef + 256) << ix->grow_cand);
   s.cand_cap = (s.cand_cap + 1) & ~1u;
-  s.hash_slots = ix->user_hash_slots ? next_pow2(ix->user_hash_slots) : next_pow2((uint32_t)(1.6 * (600 + 4 * ef)));
+  s.hash_slots = ix->user_hash_slots ? next_pow2(ix->user_hash_slots)
+                                     : next_pow2((uint32_t)(1.6 * (600 + 4 * ef))) << ix->grow_hash;
   const uint32_t dim = (uint32_t)ix->info.dim;
   // shrink the first-pass shape if it does not fit one CU at all
-  while (beam_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.hash_slots > 256) s.hash_slots >>= 1;
-  while (beam_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.cand_cap > 128) s.cand_cap = (s.cand_cap / 2 + 1) & ~1u;
-  if (beam_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU)
+  while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.hash_slots > 256) s.hash_slots >>= 1;
+  while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.cand_cap > 128) s.cand_cap = (s.cand_cap / 2 + 1) & ~1u;
+  if (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU)
     return fail(HS_ERR_CAPACITY, "ef/dim do not fit the 160 KiB LDS of one CU");
-  // fallback: the largest power-of-two hash that leaves at least as many bytes to the candidate heap
-  const size_t fixed = beam_lds_bytes(dim, s.ef, 0, 0);
+  // last resort: the largest power-of-two hash that leaves at least as many bytes to the candidate heap
+  const size_t fixed = strict_lds_bytes(dim, s.ef, 0, 0);
   size_t rem = kLdsPerCU - fixed;
   uint32_t hs_slots = 256;
   while ((size_t)hs_slots * 2 * 4 <= rem / 2) hs_slots *= 2;
@@ -131,12 +135,22 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   HIP_TRY(ix->cols.upload(p.cols));
   HIP_TRY(ix->up_base.upload(p.up_base));
   HIP_TRY(ix->up_ptr.upload(p.up_ptr));
+  // level-0 adjacency tiles: node i's ids padded with 0xFFFFFFFF to a fixed, 64-byte-multiple stride
+  uint32_t stride = 0;
+  if (p.max_deg0 <= 64) {
+    stride = std::max<uint32_t>(16, (uint32_t)((p.max_deg0 + 15) / 16 * 16));
+    std::vector<uint32_t> tile((size_t)p.n * stride, 0xFFFFFFFFu);
+    for (size_t i = 0; i < p.n; i++)
+      std::copy(p.cols.begin() + p.row_ptr0[i], p.cols.begin() + p.row_ptr0[i + 1], tile.begin() + i * stride);
+    HIP_TRY(ix->tile0.upload(tile));
+  }
   HIP_TRY(ix->labels.upload(p.labels));
   HIP_TRY(ix->deleted.upload(p.deleted));
-  HIP_TRY(ix->counters.alloc(4));
+  HIP_TRY(ix->counters.alloc(12));
   DevIndex &d = ix->dev;
   d.vec = ix->vec.p; d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p;
   d.up_ptr = ix->up_ptr.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
+  d.tile0 = stride ? ix->tile0.p : nullptr; d.tile_stride = stride;
   d.n = (uint32_t)p.n; d.dim = (uint32_t)p.dim; d.maxlevel = p.maxlevel; d.threshold_level = p.threshold_level;
   d.enterpoint = p.enterpoint; d.has_deleted = p.has_deleted; d.kind = p.kind; d.metric = p.metric;
   hs_info &i = ix->info;
@@ -144,7 +158,7 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   i.threshold_level = p.threshold_level; i.enterpoint = p.enterpoint; i.has_deleted = p.has_deleted;
   i.n_edges = p.cols.size(); i.max_degree0 = p.max_deg0;
   i.device_bytes = p.vec.size() * 4 + (p.row_ptr0.size() + p.cols.size() + p.up_base.size() + p.up_ptr.size()) * 4 +
-                   p.labels.size() * 8 + p.deleted.size();
+                   p.labels.size() * 8 + p.deleted.size() + (size_t)p.n * stride * 4;
   return HS_OK;
 }
 
@@ -198,6 +212,11 @@ hs_status hs_set_capacity(hs_index *ix, uint32_t cand_cap, uint32_t hash_slots) 
   ix->user_hash_slots = hash_slots;
   return HS_OK;
 }
+hs_status hs_set_exact_order(hs_index *ix, int on) {
+  if (!ix) return fail(HS_ERR_INVALID, "null index");
+  ix->exact_order = on != 0;
+  return HS_OK;
+}
 hs_status hs_index_info(const hs_index *ix, hs_info *out) {
   if (!ix || !out) return fail(HS_ERR_INVALID, "null argument");
   *out = ix->info;
@@ -220,34 +239,48 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(ix->status.ensure(nq));
   HIP_TRY(hipMemsetAsync(ix->status.p, 0, nq * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(ix->counters.p, 0, 4 * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(ix->counters.p, 0, 12 * sizeof(uint32_t), stream));
+  ix->last_nq = nq;
   SearchArgs a{};
   a.queries = d_q; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.ef = sh.ef;
   a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.mode = mode;
   a.mark_ep = (ix->info.kind == HS_KIND_SLIM && mode == HS_MODE_PQ) ? 1 : 0;
-  a.only_overflow = 0;
   a.out_labels32 = l32; a.out_labels64 = l64; a.out_dists = dd; a.out_counts = cnt; a.stats = stats;
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
-  a.status = ix->status.p; a.overflow_count = ix->counters.p;
-  HIP_TRY(launch_beam_search(ix->dev, a, stream));
+  a.status = ix->status.p;
+  const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
+                    fast_lds_bytes((uint32_t)ix->info.dim, sh.cand_cap, sh.hash_slots) <= kLdsPerCU;
+  // pass 0: every query, one wavefront each
+  a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = ix->counters.p; a.pass_id = 0;
+  HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
+  // pass 1: queries whose k-subset hinges on a distance tie -> strict kernel (reference heap mechanics)
+  if (fast) {
+    a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 2048); a.counters = ix->counters.p + 4; a.pass_id = 1;
+    HIP_TRY(launch_strict(ix->dev, a, stream));
+  }
+  // pass 2: queries that outgrew their scratch -> strict kernel with a whole CU's LDS each
   if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
-    a.only_overflow = 1;
+    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256);
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
-    a.overflow_count = ix->counters.p + 1;
-    HIP_TRY(launch_beam_search(ix->dev, a, stream));
+    a.counters = ix->counters.p + 8; a.pass_id = 2;
+    HIP_TRY(launch_strict(ix->dev, a, stream));
   }
   return HS_OK;
 }
 
 hs_status hs_search_check(hs_index *ix, void *stream) {
   if (!ix) return fail(HS_ERR_INVALID, "null index");
-  uint32_t c[4] = {0, 0, 0, 0};
+  uint32_t c[12];
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipMemcpyAsync(c, ix->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  // c[0] queries overflowed in pass 1; c[1] of those overflowed again in the fallback pass.
-  if (c[1] > 0 || (c[0] > 0 && false))
-    return fail(HS_ERR_CAPACITY, std::to_string(c[1]) + " queries exhausted the fallback on-chip scratch");
+  // learn the scratch sizes from the data: if more than 1% of a batch overflowed in the first passes,
+  // later batches start with twice the visited-set slots / candidate capacity.
+  const size_t nq = std::max<size_t>(ix->last_nq, 1);
+  if ((size_t)(c[0] + c[4]) * 100 > nq && ix->grow_hash < 4 && !ix->user_hash_slots) ix->grow_hash++;
+  if ((size_t)(c[1] + c[5]) * 100 > nq && ix->grow_cand < 4 && !ix->user_cand_cap) ix->grow_cand++;
+  if (c[8] + c[9] > 0)
+    return fail(HS_ERR_CAPACITY, std::to_string(c[8] + c[9]) + " queries exhausted even a whole CU's on-chip scratch");
   return HS_OK;
 }
 

@@ -15,15 +15,17 @@ struct DevIndex {
   const uint32_t *cols;     // n_edges : neighbour ids (level 0 first, then upper-level slices)
   const uint32_t *up_base;  // n       : first up_ptr entry of node i, 0xFFFFFFFF when level(i)==0
   const uint32_t *up_ptr;   //         : level-l slice of i = cols[up_ptr[b+l-1] .. up_ptr[b+l])
+  const uint32_t *tile0;    // n x tile_stride: level-0 ids of node i padded with 0xFFFFFFFF to one
+                            //         aligned tile (stride 16/32/48/64 ids), or null when max degree > 64
   const uint64_t *labels;   // n
   const uint8_t *deleted;   // n       : delete mark as the reference reads it
-  uint32_t n, dim;
+  uint32_t n, dim, tile_stride;
   int32_t maxlevel, threshold_level;
   uint32_t enterpoint;
   int32_t has_deleted, kind, metric;
 };
 
-enum : uint32_t { ST_TODO = 0, ST_DONE = 1, ST_OVERFLOW = 2 };
+enum : uint32_t { ST_TODO = 0, ST_DONE = 1, ST_OVERFLOW = 2, ST_HAZARD = 3 };
 
 struct SearchArgs {
   const float *queries;  // nq x dim (device)
@@ -32,22 +34,31 @@ struct SearchArgs {
   uint32_t hash_slots;   // visited-set slots (power of two)
   int32_t mode;          // hs_mode
   int32_t mark_ep;       // tag the enter point visited before the descent (slim (q,k) overloads)
-  int32_t only_overflow; // fallback pass: only queries whose status == ST_OVERFLOW
+  uint32_t select_mask;  // process query qi iff (1 << status[qi]) & select_mask
+  uint32_t grid;         // workgroups to launch (grid-stride over queries)
   uint32_t *out_labels32;
   uint64_t *out_labels64;
   float *out_dists;
   uint32_t *out_counts;
-  uint32_t *stats;       // nq x 4 {n_dist, n_hops, n_nbr, fallback_used}   (nullable)
-  Pair *raw_top;         // nq x raw_stride (nullable)
+  uint32_t *stats;       // nq x 4 {n_dist, n_hops, n_nbr, pass that answered}   (nullable)
+  Pair *raw_top;         // nq x raw_stride (nullable; strict kernel only)
   uint32_t *raw_size;    // nq
   uint32_t raw_stride;
   uint32_t *status;      // nq
-  uint32_t *overflow_count;  // single counter: queries left in ST_OVERFLOW by this pass
+  uint32_t *counters;    // [0] visited-set overflows, [1] candidate-heap overflows, [2] tie hazards  (this pass)
+  uint32_t pass_id;
 };
 
-// Bytes of dynamic LDS one query (one wavefront) needs for the given shape.
-size_t beam_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
-// Launch one wavefront per query on `stream`.
-hipError_t launch_beam_search(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+// Bytes of dynamic LDS one query (one wavefront) needs.
+size_t strict_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
+size_t fast_lds_bytes(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots);
+// Fast path availability for this shape (level-0 tile present, threshold_level == 0, k < ef <= 512).
+bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
+
+// Strict kernel: the reference's result/candidate arrays with libstdc++ heap mechanics, reference
+// output order.  Fast kernel: same traversal and candidate mechanics, result set kept as a sorted
+// register array; queries whose answer could depend on the result heap's layout are flagged ST_HAZARD.
+hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 
 }  // namespace hs

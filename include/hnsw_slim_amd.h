@@ -71,6 +71,14 @@ void hs_index_free(hs_index *ix);                        /* ~HierarchicalNSW* / 
 hs_status hs_set_ef(hs_index *ix, size_t ef);            /* setEf: hnswalg.h:184, hnswalg_slim.h:193 */
 hs_status hs_index_info(const hs_index *ix, hs_info *out);
 
+/* Output-order policy of the result set.  0 (default): the fast kernel answers, each query's entries
+ * come out sorted by ascending distance; the k-subset (ids and distances) is exactly the reference's --
+ * queries where the reference's choice depends on its heap layout (a distance tie across the k-th
+ * boundary) are detected and re-run with the reference's heap mechanics.  1: every query runs the strict
+ * kernel and HS_MODE_SLIM_IDS reproduces the reference's post-nth_element array ORDER as well
+ * (hnswalg_slim.h:2126-2130 leaves an unordered k-subset). */
+hs_status hs_set_exact_order(hs_index *ix, int on);
+
 /* On-chip scratch sizing per query (0 = automatic from ef): candidate-heap capacity and visited-set
  * hash slots (power of two).  Queries that outgrow it are re-run with a whole CU's LDS. */
 hs_status hs_set_capacity(hs_index *ix, uint32_t cand_cap, uint32_t hash_slots);
@@ -81,7 +89,8 @@ hs_status hs_set_capacity(hs_index *ix, uint32_t cand_cap, uint32_t hash_slots);
  *                          top_candidates after popping down to k, heap-array order; out_counts[nq].
  *   out_counts[nq] (nullable): number of valid entries per query (min(k, found)); unused slots hold
  *                          0xFFFFFFFF / UINT64_MAX / +inf.
- *   stats (nullable): nq x 4 uint32 {n_dist, n_hops, n_nbr_read, fallback_used}  (SURVEY.md 8d).
+ *   stats (nullable): nq x 4 uint32 {n_dist, n_hops, n_nbr_read, pass}  (SURVEY.md 8d); pass = 0 first
+ *                          pass, 1 tie re-run (strict kernel), 2 scratch-overflow re-run.
  * Synchronous: includes H2D of queries and D2H of results. */
 hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, int mode,
                           uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists,

@@ -59,7 +59,7 @@ def test_vanilla_vs_compiled_reference(hs, oracle, name, metric, dim):
         assert np.array_equal(raw["stats"][:, :3], o["counters"][:, :3])
 
 
-def _slim_case(hs, oracle, tmp_path, base, queries, dim, metric, M, efC, efs, k=10, threads=8, **slim_kw):
+def _slim_case(hs, oracle, tmp_path, base, queries, dim, metric, M, efC, efs, k=10, threads=8, fast=True, **slim_kw):
     hp, sp = str(tmp_path / "h.bin"), str(tmp_path / "s.bin")
     hs.build_hnsw(base, hp, metric=metric, M=M, ef_construction=efC, threads=threads)
     hs.convert_slim(hp, sp, dim, metric=metric, threads=threads, **slim_kw)
@@ -69,6 +69,8 @@ def _slim_case(hs, oracle, tmp_path, base, queries, dim, metric, M, efC, efs, k=
         ix.set_ef(ef)
         ox.set_ef(ef)
         o = ox.search_ids(queries, k, threads=8)
+        # --- strict kernel: the reference's array ORDER, raw heap arrays, counters ---
+        ix.set_exact_order(True)
         r = ix.search_ids(queries, k, want_dists=True, want_stats=True)
         assert np.array_equal(r["labels"], o["labels"]), f"ef={ef}: labels differ from searchKnn(q,k,tableint*)"
         assert np.array_equal(r["stats"][:, :3], o["counters"][:, :3]), f"ef={ef}: counters differ"
@@ -83,6 +85,17 @@ def _slim_case(hs, oracle, tmp_path, base, queries, dim, metric, M, efC, efs, k=
         rp = ix.search_pq(queries, k)
         assert np.array_equal(rp["cnt"], op["cnt"])
         assert _pq_sorted(rp["dists"], rp["labels"], rp["cnt"]) == _pq_sorted(op["dists"], op["labels"], op["cnt"])
+        # --- default (fast kernel + tie re-runs): identical k-subset per query, sorted by distance ---
+        ix.set_exact_order(False)
+        f = ix.search_ids(queries, k, want_dists=True, want_stats=True)
+        assert np.array_equal(np.sort(f["labels"], axis=1), np.sort(o["labels"], axis=1)), f"ef={ef}: fast-path id sets differ"
+        assert np.array_equal(f["stats"][:, :3], o["counters"][:, :3]), f"ef={ef}: fast-path counters differ"
+        first_pass = f["stats"][:, 3] == 0
+        if fast:  # the fast kernel needs threshold_level == 0 and ef > k; otherwise the strict kernel answers
+            assert np.all(np.diff(f["dists"][first_pass], axis=1) >= 0)
+        assert np.array_equal(np.sort(f["dists"], axis=1).view(np.uint32), np.sort(r["dists"], axis=1).view(np.uint32))
+        fp = ix.search_pq(queries, k)
+        assert _pq_sorted(fp["dists"], fp["labels"], fp["cnt"]) == _pq_sorted(op["dists"], op["labels"], op["cnt"])
     return ix, ox
 
 
@@ -95,7 +108,14 @@ def test_slim_from_golden_index(hs, oracle, tmp_path):
     for ef in (10, 32, 64, 200):
         ix.set_ef(ef)
         ox.set_ef(ef)
-        assert np.array_equal(ix.search_ids(g["queries"], 10)["labels"], ox.search_ids(g["queries"], 10)["labels"])
+        want = ox.search_ids(g["queries"], 10)["labels"]
+        ix.set_exact_order(True)
+        assert np.array_equal(ix.search_ids(g["queries"], 10)["labels"], want)
+        ix.set_exact_order(False)  # tie-heavy data: many queries take the tie re-run, sets still identical
+        got = ix.search_ids(g["queries"], 10, want_stats=True)
+        assert np.array_equal(np.sort(got["labels"], axis=1), np.sort(want, axis=1))
+        if ef > 10:
+            assert (got["stats"][:, 3] == 1).sum() > 0, "expected distance ties across the k-th boundary on this data"
 
 
 def test_slim_sift_like_d128(hs, oracle, tmp_path):
@@ -127,7 +147,7 @@ def test_slim_ip_d768(hs, oracle, tmp_path):
 def test_slim_threshold_level(hs, oracle, tmp_path):
     base = mixture(6000, 32, 29)
     q = mixture(200, 32, 30)
-    _slim_case(hs, oracle, tmp_path, base, q, 32, L2, 8, 100, [16, 64], threshold_level=1)
+    _slim_case(hs, oracle, tmp_path, base, q, 32, L2, 8, 100, [16, 64], fast=False, threshold_level=1)
 
 
 def test_fallback_pass_is_exact(hs, oracle, tmp_path):
@@ -137,15 +157,20 @@ def test_fallback_pass_is_exact(hs, oracle, tmp_path):
     ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 32, L2, 8, 100, [64])
     ix.set_ef(64)
     ox.set_ef(64)
+    want = ox.search_ids(q, 10)["labels"]
     ix.set_capacity(cand_cap=80, hash_slots=256)
-    r = ix.search_ids(q, 10, want_stats=True)
-    assert r["stats"][:, 3].sum() > 0, "expected some queries to take the fallback pass"
-    assert np.array_equal(r["labels"], ox.search_ids(q, 10)["labels"])
+    for exact in (True, False):
+        ix.set_exact_order(exact)
+        r = ix.search_ids(q, 10, want_stats=True)
+        assert (r["stats"][:, 3] == 2).sum() > 0, "expected some queries to take the whole-CU re-run"
+        assert np.array_equal(np.sort(r["labels"], axis=1), np.sort(want, axis=1))
+        if exact:
+            assert np.array_equal(r["labels"], want)
     ix.set_capacity(0, 0)
 
 
 def test_k_larger_than_ef_and_k_equals_n(hs, oracle, tmp_path):
     base = mixture(500, 16, 33)
     q = mixture(20, 16, 34)
-    ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 16, L2, 8, 50, [4], k=20)  # ef = max(ef_, k)
+    ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 16, L2, 8, 50, [4], k=20, fast=False)  # ef = max(ef_, k)
     assert ix.info()["n"] == 500
