@@ -59,29 +59,35 @@ __host__ __device__ inline StrictLds strict_layout(uint32_t dim, uint32_t ef, ui
   l.total = l.off_nd + 64 * 4;
   return l;
 }
+// The fast path uses the same offsets (so a tie re-run by the strict path reuses the allocation); it
+// ignores the `top` area and stores heap element i at cand slot i+1 (room for that is the +2 below).
 struct FastLds { uint32_t off_q, off_cand, off_hash, off_nid, off_nd, total; };
-__host__ __device__ inline FastLds fast_layout(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots) {
+__host__ __device__ inline FastLds fast_layout(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
+  const StrictLds t = strict_layout(dim, ef, cand_cap + 2, hash_slots);
   FastLds l;
-  l.off_q = 0;
-  l.off_cand = align_up(dim * 4, 16);
-  l.off_hash = l.off_cand + align_up((cand_cap + 2) * 8, 16);  // heap element i lives at slot i+1
-  l.off_nid = l.off_hash + hash_slots * 4;
-  l.off_nd = l.off_nid + 64 * 4;
-  l.total = l.off_nd + 64 * 4;
+  l.off_q = t.off_q; l.off_cand = t.off_cand; l.off_hash = t.off_hash; l.off_nid = t.off_nid; l.off_nd = t.off_nd;
+  l.total = t.total;
   return l;
 }
 size_t strict_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
   return strict_layout(dim, ef, cand_cap, hash_slots).total;
 }
-size_t fast_lds_bytes(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots) {
-  return fast_layout(dim, cand_cap, hash_slots).total;
+size_t fast_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
+  return fast_layout(dim, ef, cand_cap, hash_slots).total;
 }
 bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
   return ix.tile0 != nullptr && ix.threshold_level == 0 && ef > k && ef <= 512;
 }
 
 // ---- wave helpers -------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wavefront per workgroup
+// One wavefront per workgroup: LDS operations of a wave execute in issue order, so lanes see each other's
+// LDS writes without s_barrier; all that is needed is that the COMPILER keeps the order.  (__syncthreads()
+// would also drain vmcnt, i.e. stall on every global load still in flight -- the adjacency / row reads this
+// kernel deliberately keeps outstanding while it works on the LDS heap.)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 // whole-wave shift right by one lane (DPP wave_shr:1, a single VALU op on GFX9); lane 0 receives `carry`
@@ -89,8 +95,15 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t carry, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// DPP move within a row of 16 lanes (row_shr / row_shl): one VALU op, no LDS round trip.  Lanes whose
+// source falls outside the row keep their own value; callers only consume in-row results.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+
 struct Counters {
-  uint32_t n_dist, n_hops, n_nbr, n_ins;
+  uint32_t n_dist, n_hops, n_nbr;
 #ifdef HS_PROFILE
   unsigned long long t[8];  // cycles: 0 pop, 1 adjacency, 2 visited, 3 distances, 4 accept, 5 upper, 6 init, 7 final
 #endif
@@ -98,102 +111,180 @@ struct Counters {
 // Diagnostic build only (make prof): per-phase shader-clock stamps, written behind the stats block; the
 // product build compiles these to nothing.
 #ifdef HS_PROFILE
-#define HS_T0() unsigned long long _t0 = clock64()
+#define HS_T0() unsigned long long _t0 = clock64(); const unsigned long long _w0 = wall_clock64(); (void)_w0
+#define HS_WALL(st) do { (st).t[6] = wall_clock64() - _w0; (st).t[7] = _w0; } while (0)
 #define HS_T0_RESET() _t0 = clock64()
 #define HS_LAP(st, i) do { unsigned long long _t1 = clock64(); (st).t[i] += _t1 - _t0; _t0 = _t1; } while (0)
 #else
 #define HS_T0() do {} while (0)
+#define HS_WALL(st) do {} while (0)
 #define HS_T0_RESET() do {} while (0)
 #define HS_LAP(st, i) do {} while (0)
 #endif
 
-// Visited-set insert: true when `id` was not present (visited_list_pool.h semantics: test-and-mark).
-__device__ __forceinline__ bool hash_insert(uint32_t *tab, uint32_t mask, uint32_t id) {
-  uint32_t h = (id * 2654435761u) >> 7;
+// Visited set (visited_list_pool.h semantics: test-and-mark, exact).  Tier 1: open addressing in LDS,
+// filled to 75 %.  A query that visits more than that freezes tier 1 (read-only from then on) and
+// continues in a per-query tier-2 table in global memory (cleared lazily by the wave itself), so a long
+// query degrades to L2-latency probes instead of being thrown away and re-run.
+struct Visited {
+  uint32_t *t1, *t2;
+  uint32_t slots1, limit1, slots2, limit2;
+  uint32_t n1, n2;
+  bool spilled;
+};
+__device__ __forceinline__ void vis_init(Visited &v, const SearchArgs &a, uint32_t qi, uint32_t *lds_tab, int lane) {
+  v.t1 = lds_tab;
+  v.slots1 = a.hash_slots;
+  v.limit1 = a.hash_slots - (a.hash_slots >> 2);
+  v.t2 = a.spill ? a.spill + (size_t)qi * a.spill_slots : nullptr;
+  v.slots2 = a.spill_slots;
+  v.limit2 = a.spill_slots - (a.spill_slots >> 2);
+  v.n1 = v.n2 = 0;
+  v.spilled = false;
+  for (uint32_t i = lane; i < a.hash_slots; i += 64) lds_tab[i] = kEmpty;
+}
+// Call (wave-uniformly) before up to m inserts.  Returns false when even tier 2 is exhausted.
+__device__ __forceinline__ bool vis_reserve(Visited &v, uint32_t m, const SearchArgs &a, int lane) {
+  if (!v.spilled) {
+    if (v.n1 + m <= v.limit1) return true;
+    if (!v.t2) return false;
+    for (uint32_t i = lane; i < v.slots2; i += 64) v.t2[i] = kEmpty;
+    __threadfence_block();
+    v.spilled = true;
+    if (lane == 0) atomicAdd(a.counters + 3, 1u);
+  }
+  return v.n2 + m <= v.limit2;
+}
+__device__ __forceinline__ void vis_commit(Visited &v, uint32_t cnt) {
+  if (v.spilled) v.n2 += cnt;
+  else v.n1 += cnt;
+}
+// Both tiers are arrays of 4-slot buckets probed with one 16-byte read: an id sits in the first bucket,
+// in probe order from its home bucket, that had a free slot when it arrived (nothing is ever deleted), so
+// a lookup ends at the first bucket that contains the id or still has a free slot.
+__device__ __forceinline__ int bucket_scan(const uint4 &w, uint32_t id) {  // -2 found, -1 full, else free slot
+  if (w.x == id || w.y == id || w.z == id || w.w == id) return -2;
+  return w.x == kEmpty ? 0 : w.y == kEmpty ? 1 : w.z == kEmpty ? 2 : w.w == kEmpty ? 3 : -1;
+}
+__device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
+  const uint32_t h = id * 2654435761u;
+  const uint32_t nb1 = v.slots1 >> 2;
+  uint32_t b = __umulhi(h, nb1);
   while (true) {
-    h &= mask;
-    const uint32_t old = atomicCAS(&tab[h], kEmpty, id);
-    if (old == kEmpty) return true;
-    if (old == id) return false;
-    h++;
+    const uint4 w = reinterpret_cast<const uint4 *>(v.t1)[b];
+    const int e = bucket_scan(w, id);
+    if (e == -2) return false;
+    if (e >= 0) {
+      if (v.spilled) break;  // tier 1 is frozen: the id is not in it
+      const uint32_t old = atomicCAS(&v.t1[b * 4 + e], kEmpty, id);
+      if (old == kEmpty) return true;
+      if (old == id) return false;
+      continue;  // another lane of this wave took the slot: look at the bucket again
+    }
+    if (++b == nb1) b = 0;
+  }
+  const uint32_t nb2 = v.slots2 >> 2;
+  b = __umulhi(h, nb2);
+  while (true) {
+    const uint4 w = reinterpret_cast<const uint4 *>(v.t2)[b];
+    const int e = bucket_scan(w, id);
+    if (e == -2) return false;
+    if (e >= 0) {
+      const uint32_t old = atomicCAS(&v.t2[b * 4 + e], kEmpty, id);
+      if (old == kEmpty) return true;
+      if (old == id) return false;
+      continue;
+    }
+    if (++b == nb2) b = 0;
   }
 }
 
 // Distances query -> rows nid[0..cnt), 16 rows per pass, 4 lanes per row; nd[j] receives the value.
-// `between()` runs after the first pass's first eight 16-byte loads per lane have been ISSUED and before
-// they are consumed: LDS-only work placed there (the candidate heap's pop) hides under the HBM latency.
+// D16 = dim/16 when known at compile time (d=128 -> 8: eight 16-byte loads per lane, fully unrolled), 0 =
+// runtime dim.  `between()` runs after the first pass's row loads have been ISSUED and before they are
+// consumed: LDS-only work placed there (the candidate heap's pop) hides under the HBM latency.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int METRIC, class Hook = NoHook>
+
+template <int METRIC>
+__device__ __forceinline__ float lane4_reduce(const float (&acc)[4], int sub, bool &owner) {
+  if (METRIC == METRIC_L2) {
+    // TmpRes[0] + TmpRes[1] + ... + TmpRes[15], left to right (space_l2.h:49-51)
+    float r = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const float p = dpp_f<0x111>(r);  // row_shr:1 -- the running sum of the lane to the left (same 4-lane group)
+      if (sub == k) r = (((p + acc[0]) + acc[1]) + acc[2]) + acc[3];
+    }
+    owner = sub == 3;
+    return r;
+  } else {
+    // _mm512_reduce_add_ps: halves 16 -> 8 -> 4 -> 2 -> 1 (space_ip.h:197), then 1 - ip (:201-204)
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) h[i] = acc[i] + dpp_f<0x102>(acc[i]);  // row_shl:2: lane+2 of the group
+#pragma unroll
+    for (int i = 0; i < 4; i++) h[i] = h[i] + dpp_f<0x101>(h[i]);      // row_shl:1: lane+1
+    const float a0 = h[0] + h[2], a1 = h[1] + h[3];
+    const float ip = a0 + a1;
+    owner = sub == 0;
+    return 1.0f - ip;
+  }
+}
+template <int METRIC>
+__device__ __forceinline__ void step4(float (&acc)[4], const float4 &q4, const float4 &x4) {
+  const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+  const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+  if (METRIC == METRIC_L2) l2_step4(acc, q, x);
+  else ip_step4(acc, q, x);
+}
+
+template <int METRIC, int D16 = 0, class Hook = NoHook>
 __device__ __forceinline__ void wave_dists(const DevIndex &ix, const float *qv, const uint32_t *nid, float *nd,
                                            uint32_t cnt, int lane, Hook between = Hook()) {
   const int sub = lane & 3, grp = lane >> 2;
-  const uint32_t steps = ix.dim >> 4;
+  const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
   for (uint32_t base = 0; base < cnt; base += 16) {
     const uint32_t j = base + grp;
     const bool act = j < cnt;
-    const uint32_t id = act ? nid[j] : 0;
-    const float4 *row = reinterpret_cast<const float4 *>(ix.vec + (size_t)id * ix.dim) + sub;
-    const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
+    const uint32_t id = nid[act ? j : 0];  // idle groups re-read row 0 of the pass (cache hit) and discard
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    float4 buf[8];
-    if (act) {
+    if (D16 > 0) {
+      const float4 *row = reinterpret_cast<const float4 *>(ix.vec + (size_t)id * (D16 * 16)) + sub;
+      float4 buf[D16 <= 8 ? (D16 > 0 ? D16 : 1) : 8];
+      constexpr int B = D16 <= 8 ? D16 : 8;
+      static_assert(D16 <= 8 || D16 % 8 == 0 || true, "");
 #pragma unroll
-      for (int i = 0; i < 8; i++)
-        if ((uint32_t)i < steps) buf[i] = row[i * 4];
+      for (int i = 0; i < B; i++) buf[i] = row[i * 4];
+      if (base == 0) between();
+#pragma unroll
+      for (int i = 0; i < B; i++) step4<METRIC>(acc, qq[i * 4], buf[i]);
+      for (int s = B; s < D16; s++) step4<METRIC>(acc, qq[s * 4], row[s * 4]);
+    } else {
+      const uint32_t steps = ix.dim >> 4;
+      const float4 *row = reinterpret_cast<const float4 *>(ix.vec + (size_t)id * ix.dim) + sub;
+      float4 buf[2];  // every supported dim has steps >= 1; first chunk of up to two loads goes out early
+      buf[0] = row[0];
+      buf[1] = steps > 1 ? row[4] : buf[0];
+      if (base == 0) between();
+      step4<METRIC>(acc, qq[0], buf[0]);
+      if (steps > 1) step4<METRIC>(acc, qq[4], buf[1]);
+#pragma unroll 6
+      for (uint32_t s2 = 2; s2 < steps; s2++) step4<METRIC>(acc, qq[s2 * 4], row[s2 * 4]);
     }
-    if (base == 0) between();
-    if (act) {
-      for (uint32_t s0 = 0; s0 < steps; s0 += 8) {
-        float4 nxt[8];
-        if (s0 + 8 < steps) {
-#pragma unroll
-          for (int i = 0; i < 8; i++)
-            if (s0 + 8 + i < steps) nxt[i] = row[(s0 + 8 + i) * 4];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          if (s0 + i < steps) {
-            const float4 q4 = qq[(s0 + i) * 4];
-            const float x[4] = {buf[i].x, buf[i].y, buf[i].z, buf[i].w};
-            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            if (METRIC == METRIC_L2) l2_step4(acc, q, x);
-            else ip_step4(acc, q, x);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) buf[i] = nxt[i];
-      }
-      if (METRIC == METRIC_L2) {
-        // TmpRes[0] + TmpRes[1] + ... + TmpRes[15], left to right (space_l2.h:49-51)
-        float r = ((acc[0] + acc[1]) + acc[2]) + acc[3];
-#pragma unroll
-        for (int k = 1; k < 4; k++) {
-          const float p = __shfl_up(r, 1, 64);
-          if (sub == k) r = (((p + acc[0]) + acc[1]) + acc[2]) + acc[3];
-        }
-        if (sub == 3) nd[j] = r;
-      } else {
-        // _mm512_reduce_add_ps: halves 16 -> 8 -> 4 -> 2 -> 1 (space_ip.h:197), then 1 - ip (:201-204)
-        float h[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) h[i] = acc[i] + __shfl_down(acc[i], 2, 64);
-#pragma unroll
-        for (int i = 0; i < 4; i++) h[i] = h[i] + __shfl_down(h[i], 1, 64);
-        const float a0 = h[0] + h[2], a1 = h[1] + h[3];
-        const float ip = a0 + a1;
-        if (sub == 0) nd[j] = 1.0f - ip;
-      }
-    }
+    bool owner;
+    const float r = lane4_reduce<METRIC>(acc, sub, owner);
+    if (act && owner) nd[j] = r;
   }
 }
 
 // Shared prologue: stage the query, clear the visited set, entry distance, upper-layer greedy descent
 // (hnswalg_slim.h:2033-2078, hnswalg.h:1385-1415).  Leaves (cur, curdist) = level-0 entry.
 template <int METRIC>
-__device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a, uint32_t qi, float *qv, uint32_t *hash,
-                                        uint32_t *nid, float *nd, Counters &c, uint32_t &cur, float &curdist, int lane) {
+__device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a, uint32_t qi, float *qv, Visited &vis,
+                                        uint32_t *hash, uint32_t *nid, float *nd, Counters &c, uint32_t &cur,
+                                        float &curdist, int lane) {
   for (uint32_t i = lane; i < ix.dim; i += 64) qv[i] = a.queries[(size_t)qi * ix.dim + i];
-  for (uint32_t i = lane; i < a.hash_slots; i += 64) hash[i] = kEmpty;
+  vis_init(vis, a, qi, hash, lane);
   cur = ix.enterpoint;
   if (lane == 0) nid[0] = cur;
   wave_sync();
@@ -201,17 +292,17 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
   wave_sync();
   curdist = unif(nd[0]);
   c.n_dist = 1;
-  c.n_hops = c.n_nbr = c.n_ins = 0;
+  c.n_hops = c.n_nbr = 0;
   if (a.mark_ep) {  // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
-    if (lane == 0) hash_insert(hash, a.hash_slots - 1, cur);
-    c.n_ins++;
+    if (lane == 0) vis_insert(vis, cur);
+    vis.n1++;
   }
   for (int lvl = ix.maxlevel; lvl > ix.threshold_level; lvl--) {
     bool changed = true;
     while (changed) {
       changed = false;
       c.n_hops++;
-      const uint32_t b = ix.up_base[cur];
+      const uint32_t b = uni(ix.up_base[cur]);
       if (b == kNone) continue;
       const uint32_t s = uni(ix.up_ptr[b + lvl - 1]), e = uni(ix.up_ptr[b + lvl]);
       for (uint32_t base = s; base < e; base += 64) {
@@ -232,6 +323,8 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
           const uint32_t ol = __shfl_xor(l, off, 64);
           if (od < d || (od == d && ol < l)) { d = od; l = ol; }
         }
+        d = unif(d);  // every lane holds the same (d, l): tell the compiler so the branch below is scalar
+        l = uni(l);
         if (l < m && d < curdist) {  // hnswalg_slim.h:2071-2075
           curdist = d;
           cur = uni(nid[l]);
@@ -272,10 +365,8 @@ struct SState { uint32_t top_size, cand_size; float lb; };
 // Returns 0 ok, 1 visited-set overflow, 2 candidate-heap overflow.
 template <int METRIC>
 __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, bool bare, const float *qv, Pair *top,
-                           Pair *cand, uint32_t *hash, uint32_t *nid, float *nd, SState &st, Counters &c, int lane) {
+                           Pair *cand, Visited &vis, uint32_t *nid, float *nd, SState &st, Counters &c, int lane) {
   const uint32_t ef = a.ef;
-  const uint32_t hmask = a.hash_slots - 1;
-  const uint32_t hash_limit = a.hash_slots - (a.hash_slots >> 2);
   HS_T0();
   while (true) {
     wave_sync();
@@ -295,7 +386,7 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
       s = ix.row_ptr0[cid];
       e = ix.row_ptr0[cid + 1];
     } else {
-      const uint32_t b = ix.up_base[cid];
+      const uint32_t b = uni(ix.up_base[cid]);
       if (b == kNone) continue;  // neighbors == nullptr (:247-249)
       s = ix.up_ptr[b + level - 1];
       e = ix.up_ptr[b + level];
@@ -304,7 +395,7 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
     e = uni(e);
     for (uint32_t base = s; base < e; base += 64) {
       const uint32_t m = min(64u, e - base);
-      if (c.n_ins + m > hash_limit) return 1;
+      if (!vis_reserve(vis, m, a, lane)) return 1;
       if (st.cand_size + m > a.cand_cap) return 2;
       uint32_t id = 0;
       bool isnew = false;
@@ -313,7 +404,7 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
       id = __shfl(id, lane, 64);  // force the load to land before the stamp
 #endif
       HS_LAP(c, 1);
-      if ((uint32_t)lane < m) isnew = hash_insert(hash, hmask, id);  // :392-393
+      if ((uint32_t)lane < m) isnew = vis_insert(vis, id);  // :392-393
       const unsigned long long nm = __ballot(isnew);
       const uint32_t cnt = __popcll(nm);
       c.n_nbr += m;
@@ -321,7 +412,7 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
       wave_sync();
       if (isnew) nid[__popcll(nm & ((1ull << lane) - 1ull))] = id;  // unvisited ids, adjacency order
       wave_sync();
-      c.n_ins += cnt;
+      vis_commit(vis, cnt);
       c.n_dist += cnt;
       HS_LAP(c, 2);
       wave_dists<METRIC>(ix, qv, nid, nd, cnt, lane);  // :395-396
@@ -379,16 +470,17 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
   HS_T0();
   uint32_t cur;
   float curdist;
-  descend<METRIC>(ix, a, qi, qv, hash, nid, nd, c, cur, curdist, lane);
+  Visited vis;
+  descend<METRIC>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
   HS_LAP(c, 5);
 
   // ---- level-0 (and threshold-level) beams ----------------------------------------------------
   const bool bare = !ix.has_deleted;  // hnswalg_slim.h:2114, hnswalg.h:1421 (no filter on this path)
-  const bool ep_deleted = ix.deleted[cur] != 0;
+  const bool ep_deleted = uni(ix.deleted[cur]) != 0;
   if (ix.kind == 0) c.n_dist++;  // searchBaseLayerST recomputes the entry distance (hnswalg.h:351)
   wave_sync();
   if (lane == 0) {
-    hash_insert(hash, a.hash_slots - 1, cur);  // visited_array[currObj] = tag (hnswalg_slim.h:2102)
+    vis_insert(vis, cur);  // visited_array[currObj] = tag (hnswalg_slim.h:2102)
     if (ix.kind == 0 && !bare && ep_deleted) {  // hnswalg.h:359-362
       cand[0].d = FLT_MAX;
       cand[0].id = cur;
@@ -398,7 +490,7 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
       cand[0] = top[0];
     }
   }
-  c.n_ins++;
+  vis.n1++;
   SState st;
   st.cand_size = 1;
   if (ix.kind == 0 && !bare && ep_deleted) {
@@ -410,7 +502,7 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
   }
   int rc = 0;
   for (int lvl = min(ix.threshold_level, ix.maxlevel); lvl > 0 && rc == 0; lvl--) {  // hnswalg_slim.h:2108-2113
-    rc = strict_beam<METRIC>(ix, a, lvl, /*bare=*/false, qv, top, cand, hash, nid, nd, st, c, lane);
+    rc = strict_beam<METRIC>(ix, a, lvl, /*bare=*/false, qv, top, cand, vis, nid, nd, st, c, lane);
     // next beam starts from candidate_set <- copy of top_candidates (+ make_heap) (:228-233, :327-332)
     wave_sync();
     if (lane == 0) {
@@ -419,7 +511,7 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
     }
     st.cand_size = st.top_size;
   }
-  if (rc == 0) rc = strict_beam<METRIC>(ix, a, 0, bare, qv, top, cand, hash, nid, nd, st, c, lane);
+  if (rc == 0) rc = strict_beam<METRIC>(ix, a, 0, bare, qv, top, cand, vis, nid, nd, st, c, lane);
   wave_sync();
   if (rc != 0) {
     flag_query(a, qi, ST_OVERFLOW, rc - 1, lane);
@@ -469,16 +561,19 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
 // Candidate min-heap in LDS, element i stored at slot i+1 so that the two children of any node share one
 // 16-byte-aligned ds_read_b128.  Same sift decisions as std::push_heap/pop_heap with
 // compare_by_first_rev (hnswalg_slim.h:177-183); executed by one lane.
-__device__ __forceinline__ void cand_push(uint2 *h, uint32_t n /*size incl. new*/, float d, uint32_t id) {
-  uint32_t hole = n - 1;
-  while (hole > 0) {
-    const uint32_t parent = (hole - 1) >> 1;
-    const uint2 p = h[parent + 1];
-    if (!(__uint_as_float(p.x) > d)) break;
-    h[hole + 1] = p;
-    hole = parent;
-  }
-  h[hole + 1] = make_uint2(__float_as_uint(d), id);
+// std::push_heap == std::__push_heap(first, hole = n-1, top = 0, value): the value rises past every
+// consecutive ancestor that compares strictly greater.  All ancestors of slot n-1 are known up front
+// ((n >> t) - 1 for t = 1, 2, ...), so the whole wave does it in one read and one write round: lane t-1
+// reads ancestor t, a ballot finds where the rise stops, the passed ancestors each move one level down.
+__device__ __forceinline__ void cand_push(uint2 *h, uint32_t n /*size incl. new*/, float d, uint32_t id, int lane) {
+  const uint32_t anc = n >> (lane + 1);          // (index + 1) of this lane's ancestor; 0 = beyond the root
+  const bool has = anc != 0 && lane < 31;
+  uint2 p = make_uint2(0, 0);
+  if (has) p = h[anc];                           // element anc-1 lives at slot anc
+  const unsigned long long rises = __ballot(has && __uint_as_float(p.x) > d);
+  const uint32_t r = __ffsll((long long)~rises) - 1;  // number of consecutive ancestors passed
+  if ((uint32_t)lane < r) h[n >> lane] = p;      // ancestor t moves to the path node below it ((n >> (t-1)) - 1)
+  if ((uint32_t)lane == r) h[n >> r] = make_uint2(__float_as_uint(d), id);
 }
 __device__ __forceinline__ void cand_pop(uint2 *h, uint32_t n /*size before pop*/) {
   if (n <= 1) return;
@@ -539,18 +634,16 @@ __device__ __forceinline__ void top_insert(float (&tk)[S], uint32_t (&ti)[S], ui
   size = min(size + 1, ef);
 }
 
-template <int METRIC, int S>
-__device__ void search_one_fast(const DevIndex &ix, const SearchArgs &a, const uint32_t qi, unsigned char *smem) {
+template <int METRIC, int S, int D16>
+__device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
-  const FastLds L = fast_layout(ix.dim, a.cand_cap, a.hash_slots);
+  const FastLds L = fast_layout(ix.dim, a.ef, a.cand_cap, a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
   uint2 *cand = reinterpret_cast<uint2 *>(smem + L.off_cand);
   uint32_t *hash = reinterpret_cast<uint32_t *>(smem + L.off_hash);
   uint32_t *nid = reinterpret_cast<uint32_t *>(smem + L.off_nid);
   float *nd = reinterpret_cast<float *>(smem + L.off_nd);
   const uint32_t k = a.k, ef = a.ef;
-  const uint32_t hmask = a.hash_slots - 1;
-  const uint32_t hash_limit = a.hash_slots - (a.hash_slots >> 2);
   Counters c;
 #ifdef HS_PROFILE
   for (int i = 0; i < 8; i++) c.t[i] = 0;
@@ -558,24 +651,31 @@ __device__ void search_one_fast(const DevIndex &ix, const SearchArgs &a, const u
   HS_T0();
   uint32_t cur;
   float curdist;
-  descend<METRIC>(ix, a, qi, qv, hash, nid, nd, c, cur, curdist, lane);
+  Visited vis;
+  descend<METRIC>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
   HS_LAP(c, 5);
 
   const bool bare = !ix.has_deleted;
-  const bool ep_deleted = ix.deleted[cur] != 0;
+  const bool ep_deleted = uni(ix.deleted[cur]) != 0;
   if (ix.kind == 0) c.n_dist++;  // hnswalg.h:351
   float tk[S];
   uint32_t ti[S];
 #pragma unroll
   for (int s = 0; s < S; s++) { tk[s] = FLT_MAX; ti[s] = 0; }
-  uint32_t top_size = 0, cand_size = 1;
+  uint32_t top_size = 0;
   float lb;
+  // the node to expand next and its distance == candidate_set[0] once every pending push is applied
+  float next_d = (ix.kind == 0 && !bare && ep_deleted) ? FLT_MAX : curdist;
+  uint32_t next_id = cur;
+  uint32_t cand_size = 0;            // heap entries physically in LDS
+  unsigned long long pending = 1ull; // accepted entries of nd/nid still to be pushed (bit j = entry j)
   wave_sync();
   if (lane == 0) {
-    hash_insert(hash, hmask, cur);  // hnswalg_slim.h:2102
-    cand[1] = make_uint2(__float_as_uint((ix.kind == 0 && !bare && ep_deleted) ? FLT_MAX : curdist), cur);
+    vis_insert(vis, cur);  // hnswalg_slim.h:2102
+    nd[0] = next_d;
+    nid[0] = cur;
   }
-  c.n_ins++;
+  vis.n1++;
   if (ix.kind == 0 && !bare && ep_deleted) {  // hnswalg.h:359-362
     lb = FLT_MAX;
   } else {
@@ -583,73 +683,100 @@ __device__ void search_one_fast(const DevIndex &ix, const SearchArgs &a, const u
     lb = ep_deleted ? FLT_MAX : curdist;                       // :2104-2106
   }
   const uint32_t stride = ix.tile_stride;
+  int rc = 0;
 
   // ---- level-0 beam (hnswalg_slim.h:321-457) -----------------------------------------------------
+  // The reference pushes accepted neighbours into candidate_set one by one and pops its root at the top
+  // of the next iteration.  Which entry that root will be is known as soon as the accept decisions are:
+  // a pushed entry only rises past strictly larger parents, so it is the earliest new entry with the
+  // smallest distance if that beats the old root, else the old root.  So the next node's adjacency read
+  // is issued first and the very same pushes / pop run on the LDS heap while HBM is busy.
   while (true) {
-    wave_sync();
-    if (cand_size == 0) break;
-    const uint2 cp = cand[1];
-    const float cd = unif(__uint_as_float(cp.x));
-    const uint32_t cid = uni(cp.y);
-    if (bare ? (cd > lb) : (cd > lb && top_size == ef)) break;  // :340 / :346-347
-    // the popped node's whole level-0 list is one aligned tile: one coalesced read from the popped id
+    if (cand_size == 0 && pending == 0) break;
+    if (bare ? (next_d > lb) : (next_d > lb && top_size == ef)) break;  // :340 / :346-347
+    // the node's whole level-0 list is one aligned tile: one coalesced read from its id
     uint32_t id = kNone;
-    if ((uint32_t)lane < stride) id = ix.tile0[(size_t)cid * stride + lane];
+    if ((uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
     c.n_hops++;
+    // pending pushes of the previous expansion (:408-411), in adjacency order, under the tile read
+    wave_sync();
+    while (pending) {
+      const int j = __ffsll((long long)pending) - 1;
+      pending &= pending - 1;
+      cand_size++;
+      cand_push(cand, cand_size, unif(nd[j]), uni(nid[j]), lane);
+      wave_sync();
+    }
+    HS_LAP(c, 0);
     const bool valid = id != kNone;
     const uint32_t m = __popcll(__ballot(valid));
     HS_LAP(c, 1);
-    if (c.n_ins + m > hash_limit) { flag_query(a, qi, ST_OVERFLOW, 0, lane); return; }
-    if (cand_size + m > a.cand_cap) { flag_query(a, qi, ST_OVERFLOW, 1, lane); return; }
+    if (!vis_reserve(vis, m, a, lane)) { rc = 1; break; }
+    if (cand_size + m > a.cand_cap) { rc = 2; break; }
     bool isnew = false;
-    if (valid) isnew = hash_insert(hash, hmask, id);  // :392-393
+    if (valid) isnew = vis_insert(vis, id);  // :392-393
     const unsigned long long nm = __ballot(isnew);
     const uint32_t cnt = __popcll(nm);
     c.n_nbr += m;
-    if (cnt == 0) {
-      if (lane == 0) cand_pop(cand, cand_size);  // :353-354
-      cand_size--;
-      HS_LAP(c, 0);
-      continue;
-    }
     wave_sync();
     if (isnew) nid[__popcll(nm & ((1ull << lane) - 1ull))] = id;  // unvisited ids, adjacency order
     wave_sync();
-    c.n_ins += cnt;
+    vis_commit(vis, cnt);
     c.n_dist += cnt;
     HS_LAP(c, 2);
-    // row loads go out first; the candidate heap is re-heapified (:353-354) while they are in flight
-    wave_dists<METRIC>(ix, qv, nid, nd, cnt, lane, [&]() {
+    // row loads go out first; pop_heap (:353-354) re-heapifies the LDS array while they are in flight
+    if (cnt > 0) {
+      wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane, [&]() {
+        if (lane == 0) cand_pop(cand, cand_size);
+      });  // :395-396
+    } else {
       if (lane == 0) cand_pop(cand, cand_size);
-    });  // :395-396
+    }
     cand_size--;
     wave_sync();
     HS_LAP(c, 3);
-    // accept loop (:403-452) in adjacency order.  Once the result set is full lowerBound only decreases,
-    // so entries that fail against the current bound can never pass later: skip them wholesale.
+    // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
+    // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
     const float my_d = (uint32_t)lane < cnt ? nd[lane] : FLT_MAX;
     const uint32_t my_id = (uint32_t)lane < cnt ? nid[lane] : 0;
     unsigned long long todo = __ballot((uint32_t)lane < cnt && (top_size < ef || lb > my_d));
+    float best_d = FLT_MAX;
+    uint32_t best_id = 0;
+    bool have_best = false;
     while (todo) {
       const int j = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
       if (top_size < ef || lb > d) {  // :403-404
         const uint32_t nb = __builtin_amdgcn_readlane(my_id, j);
-        cand_size++;
-        if (lane == 0) cand_push(cand, cand_size, d, nb);  // :408-411
-        if (bare || !ix.deleted[nb]) top_insert<S>(tk, ti, top_size, ef, d, nb, lane);  // :418-448
+        pending |= 1ull << j;
+        if (!have_best || d < best_d) { best_d = d; best_id = nb; have_best = true; }
+        if (bare || uni(ix.deleted[nb]) == 0) top_insert<S>(tk, ti, top_size, ef, d, nb, lane);  // :418-448
         if (top_size > 0) lb = top_key_at<S>(tk, top_size - 1);  // :450-452
       }
     }
+    // root of candidate_set after the pending pushes
+    if (cand_size > 0) {
+      const uint2 root = cand[1];
+      next_d = unif(__uint_as_float(root.x));
+      next_id = uni(root.y);
+      if (have_best && best_d < next_d) { next_d = best_d; next_id = best_id; }
+    } else if (have_best) {
+      next_d = best_d;
+      next_id = best_id;
+    }
     HS_LAP(c, 4);
+  }
+  if (rc != 0) {
+    flag_query(a, qi, ST_OVERFLOW, rc - 1, lane);
+    return rc;
   }
   HS_T0_RESET();
   // ---- k-selection: the k smallest distances; a tie across the k-th boundary makes the reference's
-  //      choice depend on its heap layout (nth_element / pop_heap) -> strict kernel decides ----------
+  //      choice depend on its heap layout (nth_element / pop_heap) -> the strict path decides --------
   if (top_size > k && top_key_at<S>(tk, k - 1) == top_key_at<S>(tk, k)) {
-    flag_query(a, qi, ST_HAZARD, 2, lane);
-    return;
+    if (lane == 0) atomicAdd(a.counters + 2, 1u);
+    return 3;
   }
   const uint32_t valid_n = min(top_size, k);
 #pragma unroll
@@ -666,9 +793,11 @@ __device__ void search_one_fast(const DevIndex &ix, const SearchArgs &a, const u
   if (lane == 0) {
     if (a.out_counts) a.out_counts[qi] = valid_n;
     HS_LAP(c, 7);
+    HS_WALL(c);
     write_stats(a, qi, c);
     a.status[qi] = ST_DONE;
   }
+  return 0;
 }
 
 // ---- kernels: grid-stride over the queries selected by status ----------------------------------------
@@ -685,7 +814,9 @@ __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
     wave_sync();
   }
 }
-template <int METRIC, int S>
+// Fast kernel: a query whose k-subset hinges on a distance tie is answered right here by the strict path
+// (same workgroup, same LDS allocation -- the strict layout is a superset), marked pass 1 in the stats.
+template <int METRIC, int S, int D16>
 __global__ void __launch_bounds__(64) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
@@ -694,8 +825,15 @@ __global__ void __launch_bounds__(64) fast_kernel(DevIndex ix, SearchArgs a) {
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
       continue;
     }
-    search_one_fast<METRIC, S>(ix, a, qi, smem);
+    const int rc = search_one_fast<METRIC, S, D16>(ix, a, qi, smem);
     wave_sync();
+    if (rc == 3) {
+      SearchArgs b = a;
+      b.pass_id = 1;
+      b.cand_cap = a.cand_cap + 2;  // the allocation was laid out as strict_layout(dim, ef, cand_cap + 2, hash)
+      search_one_strict<METRIC>(ix, b, qi, smem);
+      wave_sync();
+    }
   }
 }
 
@@ -716,16 +854,18 @@ hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t st
                                 : launch(strict_kernel<METRIC_IP>, ix, a, lds, stream);
 }
 
-template <int METRIC>
-static hipError_t launch_fast_m(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
-  if (a.ef <= 64) return launch(fast_kernel<METRIC, 1>, ix, a, lds, stream);
-  if (a.ef <= 128) return launch(fast_kernel<METRIC, 2>, ix, a, lds, stream);
-  if (a.ef <= 256) return launch(fast_kernel<METRIC, 4>, ix, a, lds, stream);
-  return launch(fast_kernel<METRIC, 8>, ix, a, lds, stream);
+template <int METRIC, int D16>
+static hipError_t launch_fast_md(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
+  if (a.ef <= 64) return launch(fast_kernel<METRIC, 1, D16>, ix, a, lds, stream);
+  if (a.ef <= 128) return launch(fast_kernel<METRIC, 2, D16>, ix, a, lds, stream);
+  if (a.ef <= 256) return launch(fast_kernel<METRIC, 4, D16>, ix, a, lds, stream);
+  return launch(fast_kernel<METRIC, 8, D16>, ix, a, lds, stream);
 }
 hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
-  const size_t lds = fast_lds_bytes(ix.dim, a.cand_cap, a.hash_slots);
-  return ix.metric == METRIC_L2 ? launch_fast_m<METRIC_L2>(ix, a, lds, stream) : launch_fast_m<METRIC_IP>(ix, a, lds, stream);
+  const size_t lds = fast_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
+  if (ix.metric == METRIC_L2)
+    return ix.dim == 128 ? launch_fast_md<METRIC_L2, 8>(ix, a, lds, stream) : launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
+  return launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
 }
 
 }  // namespace hs

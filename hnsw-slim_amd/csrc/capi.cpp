@@ -73,6 +73,7 @@ struct hs_index {
   DevBuf<uint64_t> labels;
   DevBuf<uint8_t> deleted;
   // per-call workspace (grow-only)
+  DevBuf<uint32_t> spill;  // visited-set tier 2, nq x kSpillSlots
   DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, -}
   DevBuf<float> wq, wdist;
   DevBuf<uint32_t> wl32, wcnt, wstats, wrawsz;
@@ -91,6 +92,7 @@ struct Shape {
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
+static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
 
 static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
@@ -98,8 +100,9 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   s.ef = (uint32_t)ef;
   s.cand_cap = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((3 * ef + 256) << ix->grow_cand);
   s.cand_cap = (s.cand_cap + 1) & ~1u;
-  s.hash_slots = ix->user_hash_slots ? next_pow2(ix->user_hash_slots)
-                                     : next_pow2((uint32_t)(1.6 * (600 + 4 * ef))) << ix->grow_hash;
+  // tier-1 visited set: sized so that most queries never leave LDS (75 % fill); the rest spill to tier 2
+  const uint32_t want = (uint32_t)((450 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash) / 0.75);
+  s.hash_slots = ix->user_hash_slots ? (ix->user_hash_slots + 63) / 64 * 64 : (want + 63) / 64 * 64;
   const uint32_t dim = (uint32_t)ix->info.dim;
   // shrink the first-pass shape if it does not fit one CU at all
   while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.hash_slots > 256) s.hash_slots >>= 1;
@@ -238,6 +241,7 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   if (ps != HS_OK) return ps;
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(ix->status.ensure(nq));
+  HIP_TRY(ix->spill.ensure(nq * (size_t)kSpillSlots));
   HIP_TRY(hipMemsetAsync(ix->status.p, 0, nq * sizeof(uint32_t), stream));
   HIP_TRY(hipMemsetAsync(ix->counters.p, 0, 12 * sizeof(uint32_t), stream));
   ix->last_nq = nq;
@@ -248,16 +252,13 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   a.out_labels32 = l32; a.out_labels64 = l64; a.out_dists = dd; a.out_counts = cnt; a.stats = stats;
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
   a.status = ix->status.p;
+  a.spill = ix->spill.p; a.spill_slots = kSpillSlots;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
-                    fast_lds_bytes((uint32_t)ix->info.dim, sh.cand_cap, sh.hash_slots) <= kLdsPerCU;
+                    fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap, sh.hash_slots) <= kLdsPerCU;
   // pass 0: every query, one wavefront each
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = ix->counters.p; a.pass_id = 0;
   HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
-  // pass 1: queries whose k-subset hinges on a distance tie -> strict kernel (reference heap mechanics)
-  if (fast) {
-    a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 2048); a.counters = ix->counters.p + 4; a.pass_id = 1;
-    HIP_TRY(launch_strict(ix->dev, a, stream));
-  }
+  // (queries whose k-subset hinges on a distance tie are re-run inside the fast kernel by the strict path)
   // pass 2: queries that outgrew their scratch -> strict kernel with a whole CU's LDS each
   if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
     a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256);
@@ -277,7 +278,7 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   // learn the scratch sizes from the data: if more than 1% of a batch overflowed in the first passes,
   // later batches start with twice the visited-set slots / candidate capacity.
   const size_t nq = std::max<size_t>(ix->last_nq, 1);
-  if ((size_t)(c[0] + c[4]) * 100 > nq && ix->grow_hash < 4 && !ix->user_hash_slots) ix->grow_hash++;
+  if ((size_t)c[3] * 10 > nq && ix->grow_hash < 8 && !ix->user_hash_slots) ix->grow_hash++;
   if ((size_t)(c[1] + c[5]) * 100 > nq && ix->grow_cand < 4 && !ix->user_cand_cap) ix->grow_cand++;
   if (c[8] + c[9] > 0)
     return fail(HS_ERR_CAPACITY, std::to_string(c[8] + c[9]) + " queries exhausted even a whole CU's on-chip scratch");

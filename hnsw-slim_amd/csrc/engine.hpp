@@ -31,7 +31,9 @@ struct SearchArgs {
   const float *queries;  // nq x dim (device)
   uint32_t nq, k, ef;    // ef = max(ef_, k)   (hnswalg_slim.h:2080)
   uint32_t cand_cap;     // candidate-heap capacity (entries)
-  uint32_t hash_slots;   // visited-set slots (power of two)
+  uint32_t hash_slots;   // visited-set tier-1 (LDS) slots
+  uint32_t *spill;       // visited-set tier 2: nq x spill_slots words in global memory (nullable)
+  uint32_t spill_slots;
   int32_t mode;          // hs_mode
   int32_t mark_ep;       // tag the enter point visited before the descent (slim (q,k) overloads)
   uint32_t select_mask;  // process query qi iff (1 << status[qi]) & select_mask
@@ -45,13 +47,13 @@ struct SearchArgs {
   uint32_t *raw_size;    // nq
   uint32_t raw_stride;
   uint32_t *status;      // nq
-  uint32_t *counters;    // [0] visited-set overflows, [1] candidate-heap overflows, [2] tie hazards  (this pass)
+  uint32_t *counters;    // [0] visited-set overflows, [1] candidate-heap overflows, [2] tie hazards, [3] tier-2 spills (this pass)
   uint32_t pass_id;
 };
 
 // Bytes of dynamic LDS one query (one wavefront) needs.
 size_t strict_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
-size_t fast_lds_bytes(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots);
+size_t fast_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
 // Fast path availability for this shape (level-0 tile present, threshold_level == 0, k < ef <= 512).
 bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 

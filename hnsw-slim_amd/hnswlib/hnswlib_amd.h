@@ -1,0 +1,235 @@
+// hnswlib_amd.h -- header-only C++ facade that re-creates the part of the reference's hnswlib API that
+// sits on the searchKnn hot path, on top of the C ABI in include/hnsw_slim_amd.h (libhnsw_slim_amd.so).
+//
+// A caller written against the reference (include/strategy/hnsw_slim_strategy.h:38-114,
+// hnsw_slim_server.cc:59-81) keeps its code: same namespace, class names, method names, argument meaning,
+// exception type and messages.  What changes is where the work runs: loadIndex uploads the index to one
+// MI355X, searchKnn runs the HIP beam-search kernel, and the new searchKnnBatch() is the fast entry
+// (one wavefront per query; a single-query searchKnn is a batch of one and pays a kernel launch).
+//
+// Mirrors (paths relative to /root/reference/third_party/hnswlib/):
+//   hnswlib.h:125-221        labeltype, BaseFilterFunctor, DISTFUNC, SpaceInterface, AlgorithmInterface
+//   space_l2.h:208-253       L2Space            space_ip.h:342-398  InnerProductSpace
+//   hnswalg.h:17-19,78-83,184,781,1378          HierarchicalNSW<float>
+//   hnswalg_slim.h:28-30,83-87,149-152,193,753,867,1907,2030   HierarchicalNSWSlim<float>
+// Not provided (outside the search path): addPoint/updatePoint/markDelete, the diff/patch
+// protocol, stop conditions, and filter functors (host callbacks cannot run inside the kernel; passing a
+// non-null BaseFilterFunctor throws).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/hnsw_slim_amd.h"
+#include "../csrc/dist_recipe.hpp"
+
+namespace hnswlib {
+
+typedef size_t labeltype;
+typedef unsigned int tableint;
+
+class BaseFilterFunctor {
+ public:
+  virtual bool operator()(hnswlib::labeltype) { return true; }
+  virtual ~BaseFilterFunctor() {}
+};
+
+template <typename MTYPE>
+using DISTFUNC = MTYPE (*)(const void *, const void *, const void *);
+
+template <typename MTYPE>
+class SpaceInterface {
+ public:
+  virtual size_t get_data_size() = 0;
+  virtual DISTFUNC<MTYPE> get_dist_func() = 0;
+  virtual void *get_dist_func_param() = 0;
+  virtual ~SpaceInterface() {}
+};
+
+// The host-side distance functions are the same operation-for-operation recipes the kernel uses
+// (dist_recipe.hpp), so values computed through the space agree bit for bit with search results.
+class L2Space : public SpaceInterface<float> {
+  size_t data_size_, dim_;
+  static float fn(const void *a, const void *b, const void *p) {
+    return hs::l2_row16((const float *)a, (const float *)b, *(const size_t *)p);
+  }
+ public:
+  explicit L2Space(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {
+    if (dim % 16) throw std::runtime_error("hnswlib_amd: dim % 16 != 0 is not supported yet");
+  }
+  size_t get_data_size() override { return data_size_; }
+  DISTFUNC<float> get_dist_func() override { return fn; }
+  void *get_dist_func_param() override { return &dim_; }
+};
+class InnerProductSpace : public SpaceInterface<float> {
+  size_t data_size_, dim_;
+  static float fn(const void *a, const void *b, const void *p) {
+    return hs::ip_row16((const float *)a, (const float *)b, *(const size_t *)p);
+  }
+ public:
+  explicit InnerProductSpace(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {
+    if (dim % 16) throw std::runtime_error("hnswlib_amd: dim % 16 != 0 is not supported yet");
+  }
+  size_t get_data_size() override { return data_size_; }
+  DISTFUNC<float> get_dist_func() override { return fn; }
+  void *get_dist_func_param() override { return &dim_; }
+};
+
+template <typename dist_t>
+class AlgorithmInterface {
+ public:
+  virtual void addPoint(const void *datapoint, labeltype label, bool replace_deleted = false) = 0;
+  virtual std::priority_queue<std::pair<dist_t, labeltype>> searchKnn(const void *, size_t,
+                                                                     BaseFilterFunctor *isIdAllowed = nullptr) const = 0;
+  virtual std::vector<std::pair<dist_t, labeltype>> searchKnnCloserFirst(const void *query_data, size_t k,
+                                                                        BaseFilterFunctor *isIdAllowed = nullptr) const {
+    std::vector<std::pair<dist_t, labeltype>> result;  // hnswlib.h:203-221
+    auto ret = searchKnn(query_data, k, isIdAllowed);
+    size_t sz = ret.size();
+    result.resize(sz);
+    while (!ret.empty()) {
+      result[--sz] = ret.top();
+      ret.pop();
+    }
+    return result;
+  }
+  virtual void saveIndex(const std::string &location) = 0;
+  virtual ~AlgorithmInterface() {}
+};
+
+namespace detail {
+inline void check(hs_status s) {
+  if (s != HS_OK) throw std::runtime_error(hs_last_error());  // same exception type/messages as the reference
+}
+inline int metric_of(SpaceInterface<float> *s) { return dynamic_cast<InnerProductSpace *>(s) ? HS_METRIC_IP : HS_METRIC_L2; }
+inline size_t dim_of(SpaceInterface<float> *s) { return s->get_data_size() / sizeof(float); }
+
+// Common device-index holder.
+class DeviceIndex {
+ protected:
+  hs_index *h_ = nullptr;
+  std::string path_;
+  int metric_ = HS_METRIC_L2;
+  size_t dim_ = 0;
+  int device_ = 0;
+
+ public:
+  size_t ef_ = 10;
+  ~DeviceIndex() { hs_index_free(h_); }
+  void setDevice(int device) { device_ = device; }
+  void setEf(size_t ef) {
+    ef_ = ef;
+    if (h_) check(hs_set_ef(h_, ef));
+  }
+  hs_index *handle() const { return h_; }
+  const std::string &path() const { return path_; }
+
+ protected:
+  void load(const std::string &location, int kind, SpaceInterface<float> *s, size_t max_elements) {
+    hs_index_free(h_);
+    h_ = nullptr;
+    metric_ = metric_of(s);
+    dim_ = dim_of(s);
+    path_ = location;
+    check(hs_index_load(location.c_str(), kind, metric_, dim_, max_elements, device_, &h_));
+    ef_ = 10;  // hnswalg.h:864, hnswalg_slim.h:793
+  }
+  std::priority_queue<std::pair<float, labeltype>> search_pq(const void *q, size_t k) const {
+    std::priority_queue<std::pair<float, labeltype>> result;
+    if (!h_) return result;
+    std::vector<uint64_t> labels(k);
+    std::vector<float> dists(k);
+    uint32_t cnt = 0;
+    check(hs_search_batch(h_, (const float *)q, 1, k, HS_MODE_PQ, nullptr, labels.data(), dists.data(), &cnt, nullptr));
+    for (uint32_t i = 0; i < cnt; i++) result.emplace(dists[i], (labeltype)labels[i]);
+    return result;
+  }
+};
+}  // namespace detail
+
+template <typename dist_t>
+class HierarchicalNSW;
+
+template <>
+class HierarchicalNSW<float> : public AlgorithmInterface<float>, public detail::DeviceIndex {
+ public:
+  explicit HierarchicalNSW(SpaceInterface<float> *) {}
+  HierarchicalNSW(SpaceInterface<float> *s, const std::string &location, bool /*nmslib*/ = false, size_t max_elements = 0,
+                  bool /*allow_replace_deleted*/ = false) {
+    loadIndex(location, s, max_elements);
+  }
+  void loadIndex(const std::string &location, SpaceInterface<float> *s, size_t max_elements_i = 0) {
+    load(location, HS_KIND_HNSW, s, max_elements_i);
+  }
+  void addPoint(const void *, labeltype, bool = false) override {
+    throw std::runtime_error("hnswlib_amd: HierarchicalNSW::addPoint is not on the GPU search path (build with hs_build_hnsw)");
+  }
+  void saveIndex(const std::string &) override {
+    throw std::runtime_error("hnswlib_amd: the device index is read-only; the file it was loaded from is unchanged");
+  }
+  std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k,
+                                                             BaseFilterFunctor *isIdAllowed = nullptr) const override {
+    if (isIdAllowed) throw std::runtime_error("hnswlib_amd: filter functors are not supported on the GPU path");
+    return search_pq(query_data, k);
+  }
+  // Batched searchKnn: nq x dim queries; out_labels / out_dists nq x k (unused slots: UINT64_MAX / +inf).
+  void searchKnnBatch(const float *queries, size_t nq, size_t k, uint64_t *out_labels, float *out_dists,
+                      uint32_t *out_counts) const {
+    detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_PQ, nullptr, out_labels, out_dists, out_counts, nullptr));
+  }
+};
+
+template <typename dist_t>
+class HierarchicalNSWSlim;
+
+template <>
+class HierarchicalNSWSlim<float> : public AlgorithmInterface<float>, public detail::DeviceIndex {
+ public:
+  explicit HierarchicalNSWSlim(SpaceInterface<float> *) {}
+  HierarchicalNSWSlim(SpaceInterface<float> *s, const std::string &location, bool /*nmslib*/ = false,
+                      size_t max_elements = 0, bool /*allow_replace_deleted*/ = false) {
+    loadIndex(location, s, max_elements);
+  }
+  void loadIndex(const std::string &location, SpaceInterface<float> *s, size_t max_elements_i = 0) {
+    load(location, HS_KIND_SLIM, s, max_elements_i);
+  }
+  // convertFromHNSW (hnswalg_slim.h:867-1108) + saveIndex to `slim_location`, then load it on the device.
+  void convertFromHNSW(HierarchicalNSW<float> *hnsw, SpaceInterface<float> *s, const std::string &slim_location,
+                       int threshold_level = 0, float top_degree_percent0 = 0.02f, float top_degree_percent = 0.02f,
+                       size_t top_degree_M0 = 32, size_t low_degree_m0 = 8, size_t top_degree_M = 16,
+                       size_t low_degree_m = 4, int threads = 1) {
+    detail::check(hs_convert_slim(hnsw->path().c_str(), detail::metric_of(s), detail::dim_of(s), threshold_level,
+                                  top_degree_percent0, top_degree_percent, top_degree_M0, low_degree_m0, top_degree_M,
+                                  low_degree_m, threads, slim_location.c_str()));
+    loadIndex(slim_location, s);
+  }
+  void addPoint(const void *, labeltype, bool = false) override {
+    throw std::runtime_error("HierarchicalNSWSlim does not support addPoint");  // hnswalg_slim.h:149-152
+  }
+  void saveIndex(const std::string &) override {
+    throw std::runtime_error("hnswlib_amd: the device index is read-only; the file it was loaded from is unchanged");
+  }
+  // searchKnn(q, k, filter) / searchKnn(q, k): hnswalg_slim.h:1783-1905 / 1907-2028
+  std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k,
+                                                             BaseFilterFunctor *isIdAllowed = nullptr) const override {
+    if (isIdAllowed) throw std::runtime_error("hnswlib_amd: filter functors are not supported on the GPU path");
+    return search_pq(query_data, k);
+  }
+  // searchKnn(q, k, tableint* result): hnswalg_slim.h:2030-2131.  k labels; same k-subset as the reference,
+  // sorted by distance (call setExactOrder(true) to also reproduce the reference's array order).
+  void searchKnn(const void *query_data, size_t k, tableint *result) const {
+    if (!h_) return;  // cur_element_count_ == 0 (hnswalg_slim.h:2031-2032)
+    detail::check(hs_search_batch(h_, (const float *)query_data, 1, k, HS_MODE_SLIM_IDS, result, nullptr, nullptr, nullptr, nullptr));
+  }
+  // The fast entry: every row of `queries` in one launch.
+  void searchKnnBatch(const float *queries, size_t nq, size_t k, tableint *results) const {
+    detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_SLIM_IDS, results, nullptr, nullptr, nullptr, nullptr));
+  }
+  void setExactOrder(bool on) { detail::check(hs_set_exact_order(h_, on ? 1 : 0)); }
+};
+
+}  // namespace hnswlib

@@ -1,0 +1,80 @@
+// tests/facade_smoke.cpp -- a caller written against the reference's hnswlib API, compiled against the
+// facade instead (hnsw-slim_amd/hnswlib/hnswlib_amd.h).  Mirrors include/strategy/hnsw_slim_strategy.h:
+// L2Space(dim) -> HierarchicalNSWSlim(space, path) -> setEf -> searchKnn(q, K, out) per query.
+// usage: facade_smoke <mode> ...
+//   errors                      : CPU-safe checks of the reference's error conventions
+//   slim  <slim.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32>      : per-query searchKnn + batch
+//   hnsw  <hnsw.bin> <dim> <queries.f32> <nq> <k> <ef> <out.bin>      : priority_queue overload
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../hnsw-slim_amd/hnswlib/hnswlib_amd.h"
+
+static std::vector<float> read_f32(const char *p, size_t n) {
+  std::vector<float> v(n);
+  std::ifstream in(p, std::ios::binary);
+  in.read((char *)v.data(), n * 4);
+  return v;
+}
+
+int main(int argc, char **argv) {
+  std::string mode = argc > 1 ? argv[1] : "";
+  if (mode == "errors") {
+    hnswlib::L2Space space(32);
+    int ok = 0;
+    try {
+      hnswlib::HierarchicalNSWSlim<float> ix(&space, "/nonexistent/slim.bin");
+    } catch (std::runtime_error &e) {
+      // without a GPU the device check comes first; with one, the reference's message
+      ok += (std::string(e.what()) == "Cannot open file" || std::string(e.what()).find("no HIP device") != std::string::npos);
+    }
+    try {
+      hnswlib::HierarchicalNSWSlim<float> ix(&space);
+      ix.addPoint(nullptr, 0);
+    } catch (std::runtime_error &e) {
+      ok += std::string(e.what()) == "HierarchicalNSWSlim does not support addPoint";
+    }
+    try {
+      hnswlib::L2Space bad(30);
+    } catch (std::runtime_error &) {
+      ok++;
+    }
+    float a[16], b[16];
+    for (int i = 0; i < 16; i++) { a[i] = i; b[i] = 2 * i; }
+    hnswlib::L2Space s16(16);
+    ok += s16.get_dist_func()(a, b, s16.get_dist_func_param()) == 1240.0f;  // sum i^2, i<16
+    printf("errors ok=%d/4\n", ok);
+    return ok == 4 ? 0 : 1;
+  }
+  if (argc < 9) return 2;
+  const char *path = argv[2];
+  size_t dim = atoi(argv[3]), nq = atoi(argv[5]), k = atoi(argv[6]), ef = atoi(argv[7]);
+  auto Q = read_f32(argv[4], nq * dim);
+  hnswlib::L2Space space(dim);
+  std::ofstream out(argv[8], std::ios::binary);
+  if (mode == "slim") {
+    hnswlib::HierarchicalNSWSlim<float> ix(&space, path);
+    ix.setEf(ef);
+    ix.setExactOrder(true);
+    std::vector<hnswlib::tableint> one(k), all(nq * k);
+    for (size_t i = 0; i < nq; i++) {  // the reference's serial query loop (hnsw_slim_strategy.h:112-114)
+      ix.searchKnn(Q.data() + i * dim, k, one.data());
+      out.write((char *)one.data(), 4 * k);
+    }
+    ix.searchKnnBatch(Q.data(), nq, k, all.data());
+    out.write((char *)all.data(), 4 * nq * k);
+  } else {
+    hnswlib::HierarchicalNSW<float> ix(&space, path);
+    ix.setEf(ef);
+    for (size_t i = 0; i < nq; i++) {
+      auto r = ix.searchKnnCloserFirst(Q.data() + i * dim, k);
+      uint32_t c = r.size();
+      out.write((char *)&c, 4);
+      for (auto &p : r) { uint64_t l = p.second; out.write((char *)&p.first, 4); out.write((char *)&l, 8); }
+    }
+  }
+  return 0;
+}

@@ -174,3 +174,35 @@ def test_k_larger_than_ef_and_k_equals_n(hs, oracle, tmp_path):
     q = mixture(20, 16, 34)
     ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 16, L2, 8, 50, [4], k=20, fast=False)  # ef = max(ef_, k)
     assert ix.info()["n"] == 500
+
+
+def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
+    """hnswlib-API caller (tests/facade_smoke.cpp): per-query searchKnn(q,k,tableint*) loop + searchKnnBatch on
+    a Slim index, and searchKnnCloserFirst on a vanilla index, against the oracle."""
+    import subprocess
+    from hsutil import ROOT
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "facade_smoke")
+    assert os.path.exists(exe)
+    g = np.load(os.path.join(GOLDEN, "l2_cont_d32.npz"))
+    q = np.ascontiguousarray(g["queries"][:40])
+    qf = str(tmp_path / "q.f32")
+    q.tofile(qf)
+    hp = os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin")
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(hp, sp, 32)
+    out = str(tmp_path / "o.bin")
+    subprocess.check_call([exe, "slim", sp, "32", qf, "40", "10", "48", out])
+    got = np.fromfile(out, np.uint32).reshape(2, 40, 10)
+    ox = oracle.load(sp, "slim", L2, 32)
+    ox.set_ef(48)
+    want = ox.search_ids(q, 10)["labels"]
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    subprocess.check_call([exe, "hnsw", hp, "32", qf, "40", "10", "48", out])
+    ov = oracle.load(hp, "hnsw", L2, 32)
+    ov.set_ef(48)
+    w = ov.search_pq(q, 10)
+    rec = np.fromfile(out, np.dtype([("c", "<u4"), ("p", [("d", "<f4"), ("l", "<u8")], 10)]))
+    assert np.array_equal(rec["c"], w["cnt"])
+    # closer-first order == reverse of the priority_queue pop order
+    assert np.array_equal(rec["p"]["l"], w["labels"][:, ::-1])
+    assert rec["p"]["d"].tobytes() == np.ascontiguousarray(w["dists"][:, ::-1]).tobytes()

@@ -114,3 +114,11 @@ def test_error_conventions(hs, tmp_path):
     bad.write_bytes(open(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), "rb").read()[:5000])
     with pytest.raises(hs.HsError, match="corrupted"):
         hs.convert_slim(str(bad), str(tmp_path / "o.bin"), 32)
+
+
+def test_facade_error_conventions(hs):
+    """A caller compiled against the hnswlib-compatible facade sees the reference's exception texts."""
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "facade_smoke")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "facade_smoke"])
+    out = subprocess.run([exe, "errors"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
