@@ -136,7 +136,7 @@ __device__ __forceinline__ void vis_init(Visited &v, const SearchArgs &a, uint32
   v.t1 = lds_tab;
   v.slots1 = a.hash_slots;
   v.limit1 = a.hash_slots - (a.hash_slots >> 2);
-  v.t2 = a.spill ? a.spill + (size_t)qi * a.spill_slots : nullptr;
+  v.t2 = a.spill ? a.spill + (size_t)qi * a.spill_stride : nullptr;
   v.slots2 = a.spill_slots;
   v.limit2 = a.spill_slots - (a.spill_slots >> 2);
   v.n1 = v.n2 = 0;
@@ -238,10 +238,13 @@ __device__ __forceinline__ void step4(float (&acc)[4], const float4 &q4, const f
   else ip_step4(acc, q, x);
 }
 
-template <int METRIC, int D16 = 0, class Hook = NoHook>
-__device__ __forceinline__ void wave_dists(const DevIndex &ix, const float *qv, const uint32_t *nid, float *nd,
-                                           uint32_t cnt, int lane, Hook between = Hook()) {
+// TO_REG: instead of writing nd[j], hand the value of row j to lane j in a register (one cross-lane move,
+// no LDS write/read round trip); returned value is meaningful in lanes < cnt.
+template <int METRIC, int D16 = 0, class Hook = NoHook, bool TO_REG = false>
+__device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv, const uint32_t *nid, float *nd,
+                                            uint32_t cnt, int lane, Hook between = Hook()) {
   const int sub = lane & 3, grp = lane >> 2;
+  float out = FLT_MAX;
   const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
   for (uint32_t base = 0; base < cnt; base += 16) {
     const uint32_t j = base + grp;
@@ -273,8 +276,14 @@ __device__ __forceinline__ void wave_dists(const DevIndex &ix, const float *qv, 
     }
     bool owner;
     const float r = lane4_reduce<METRIC>(acc, sub, owner);
-    if (act && owner) nd[j] = r;
+    if (TO_REG) {
+      const float got = __shfl(r, ((lane - (int)base) & 15) * 4 + (METRIC == METRIC_L2 ? 3 : 0), 64);
+      if ((uint32_t)lane >= base && (uint32_t)lane < base + 16 && (uint32_t)lane < cnt) out = got;
+    } else {
+      if (act && owner) nd[j] = r;
+    }
   }
+  return out;
 }
 
 // Shared prologue: stage the query, clear the visited set, entry distance, upper-layer greedy descent
@@ -558,50 +567,85 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
 // =================================================================================================
 // fast kernel
 // =================================================================================================
-// Candidate min-heap in LDS, element i stored at slot i+1 so that the two children of any node share one
-// 16-byte-aligned ds_read_b128.  Same sift decisions as std::push_heap/pop_heap with
-// compare_by_first_rev (hnswalg_slim.h:177-183); executed by one lane.
+// Candidate min-heap, element i stored at slot i+1 so that the two children of any node share one aligned
+// 16-byte read.  Slots [0, L) live in LDS (L even, so a child pair never straddles), the rest in a per-query
+// region of global memory: a query whose heap outgrows its LDS share keeps going (its deepest heap levels
+// pay L2 latency) instead of being thrown away.  Same sift decisions as std::push_heap / pop_heap with
+// compare_by_first_rev (hnswalg_slim.h:177-183).
+struct CandHeap {
+  uint2 *lds, *glob;
+  uint32_t L;  // LDS slots
+};
+// T2 = false: the heap is known to fit its LDS share -> LDS-only code (no global access, so no vmcnt wait
+// is generated and the row loads in flight around the pop stay in flight).
+template <bool T2>
+__device__ __forceinline__ uint2 ch_get(const CandHeap &h, uint32_t s) {
+  if (!T2) return h.lds[s];
+  return s < h.L ? h.lds[s] : h.glob[s - h.L];
+}
+template <bool T2>
+__device__ __forceinline__ void ch_set(const CandHeap &h, uint32_t s, uint2 v) {
+  if (!T2 || s < h.L) h.lds[s] = v;
+  else h.glob[s - h.L] = v;
+}
+template <bool T2>
+__device__ __forceinline__ uint4 ch_get2(const CandHeap &h, uint32_t s /*even*/) {
+  if (!T2) return *reinterpret_cast<const uint4 *>(&h.lds[s]);
+  return s < h.L ? *reinterpret_cast<const uint4 *>(&h.lds[s]) : *reinterpret_cast<const uint4 *>(&h.glob[s - h.L]);
+}
+
 // std::push_heap == std::__push_heap(first, hole = n-1, top = 0, value): the value rises past every
 // consecutive ancestor that compares strictly greater.  All ancestors of slot n-1 are known up front
 // ((n >> t) - 1 for t = 1, 2, ...), so the whole wave does it in one read and one write round: lane t-1
 // reads ancestor t, a ballot finds where the rise stops, the passed ancestors each move one level down.
-__device__ __forceinline__ void cand_push(uint2 *h, uint32_t n /*size incl. new*/, float d, uint32_t id, int lane) {
+template <bool T2>
+__device__ __forceinline__ void cand_push_t(const CandHeap &h, uint32_t n /*size incl. new*/, float d, uint32_t id, int lane) {
   const uint32_t anc = n >> (lane + 1);          // (index + 1) of this lane's ancestor; 0 = beyond the root
   const bool has = anc != 0 && lane < 31;
   uint2 p = make_uint2(0, 0);
-  if (has) p = h[anc];                           // element anc-1 lives at slot anc
+  if (has) p = ch_get<T2>(h, anc);               // element anc-1 lives at slot anc
   const unsigned long long rises = __ballot(has && __uint_as_float(p.x) > d);
   const uint32_t r = __ffsll((long long)~rises) - 1;  // number of consecutive ancestors passed
-  if ((uint32_t)lane < r) h[n >> lane] = p;      // ancestor t moves to the path node below it ((n >> (t-1)) - 1)
-  if ((uint32_t)lane == r) h[n >> r] = make_uint2(__float_as_uint(d), id);
+  if ((uint32_t)lane < r) ch_set<T2>(h, n >> lane, p);  // ancestor t moves to the path node below it ((n >> (t-1)) - 1)
+  if ((uint32_t)lane == r) ch_set<T2>(h, n >> r, make_uint2(__float_as_uint(d), id));
 }
-__device__ __forceinline__ void cand_pop(uint2 *h, uint32_t n /*size before pop*/) {
+__device__ __forceinline__ void cand_push(const CandHeap &h, uint32_t n, float d, uint32_t id, int lane) {
+  if (n < h.L) cand_push_t<false>(h, n, d, id, lane);  // slot n is the deepest slot touched
+  else cand_push_t<true>(h, n, d, id, lane);
+}
+// std::pop_heap (one lane).  Returns nothing; the popped root was read by the caller beforehand.
+template <bool T2>
+__device__ __forceinline__ void cand_pop_t(const CandHeap &h, uint32_t n /*size before pop*/) {
   if (n <= 1) return;
-  const uint2 v = h[n];  // a[n-1]
+  const uint2 v = ch_get<T2>(h, n);  // a[n-1]
   const uint32_t len = n - 1;
   uint32_t hole = 0, child = 0;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    const uint4 two = *reinterpret_cast<const uint4 *>(&h[child]);  // a[child-1], a[child]
+    const uint4 two = ch_get2<T2>(h, child);  // a[child-1], a[child]
     const bool left = __uint_as_float(two.z) > __uint_as_float(two.x);  // comp(a[child], a[child-1])
-    h[hole + 1] = left ? make_uint2(two.x, two.y) : make_uint2(two.z, two.w);
+    ch_set<T2>(h, hole + 1, left ? make_uint2(two.x, two.y) : make_uint2(two.z, two.w));
     child = left ? child - 1 : child;
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    h[hole + 1] = h[child];  // a[child-1]
+    ch_set<T2>(h, hole + 1, ch_get<T2>(h, child));  // a[child-1]
     hole = child - 1;
   }
   const float vd = __uint_as_float(v.x);
   while (hole > 0) {
     const uint32_t parent = (hole - 1) >> 1;
-    const uint2 p = h[parent + 1];
+    const uint2 p = ch_get<T2>(h, parent + 1);
     if (!(__uint_as_float(p.x) > vd)) break;
-    h[hole + 1] = p;
+    ch_set<T2>(h, hole + 1, p);
     hole = parent;
   }
-  h[hole + 1] = v;
+  ch_set<T2>(h, hole + 1, v);
+}
+__device__ __forceinline__ void cand_pop(const CandHeap &h, uint32_t n) {
+  if (n < h.L) cand_pop_t<false>(h, n);
+  else cand_pop_t<true>(h, n);
 }
 
 // Result set as a sorted (ascending distance) register array: rank r lives in lane r % 64, slot r / 64.
@@ -639,7 +683,11 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   const int lane = threadIdx.x;
   const FastLds L = fast_layout(ix.dim, a.ef, a.cand_cap, a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
-  uint2 *cand = reinterpret_cast<uint2 *>(smem + L.off_cand);
+  CandHeap cand;
+  cand.lds = reinterpret_cast<uint2 *>(smem + L.off_cand);
+  cand.L = a.cand_cap + 2;  // cand_cap is even
+  cand.glob = reinterpret_cast<uint2 *>(a.spill + (size_t)qi * a.spill_stride + a.spill_slots);
+  const uint32_t cand_total = a.spill ? a.cand_cap + a.cand2_cap : a.cand_cap;
   uint32_t *hash = reinterpret_cast<uint32_t *>(smem + L.off_hash);
   uint32_t *nid = reinterpret_cast<uint32_t *>(smem + L.off_nid);
   float *nd = reinterpret_cast<float *>(smem + L.off_nd);
@@ -712,7 +760,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     const uint32_t m = __popcll(__ballot(valid));
     HS_LAP(c, 1);
     if (!vis_reserve(vis, m, a, lane)) { rc = 1; break; }
-    if (cand_size + m > a.cand_cap) { rc = 2; break; }
+    if (cand_size + m > cand_total) { rc = 2; break; }
     bool isnew = false;
     if (valid) isnew = vis_insert(vis, id);  // :392-393
     const unsigned long long nm = __ballot(isnew);
@@ -725,20 +773,21 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     c.n_dist += cnt;
     HS_LAP(c, 2);
     // row loads go out first; pop_heap (:353-354) re-heapifies the LDS array while they are in flight
-    if (cnt > 0) {
-      wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane, [&]() {
-        if (lane == 0) cand_pop(cand, cand_size);
-      });  // :395-396
-    } else {
+    auto pop_hook = [&]() {
       if (lane == 0) cand_pop(cand, cand_size);
+    };
+    if (cnt > 0) {
+      wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane, pop_hook);  // :395-396
+    } else {
+      pop_hook();
     }
     cand_size--;
     wave_sync();
     HS_LAP(c, 3);
-    // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
-    // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
     const float my_d = (uint32_t)lane < cnt ? nd[lane] : FLT_MAX;
     const uint32_t my_id = (uint32_t)lane < cnt ? nid[lane] : 0;
+    // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
+    // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
     unsigned long long todo = __ballot((uint32_t)lane < cnt && (top_size < ef || lb > my_d));
     float best_d = FLT_MAX;
     uint32_t best_id = 0;
@@ -757,7 +806,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     }
     // root of candidate_set after the pending pushes
     if (cand_size > 0) {
-      const uint2 root = cand[1];
+      const uint2 root = cand.lds[1];
       next_d = unif(__uint_as_float(root.x));
       next_id = uni(root.y);
       if (have_best && best_d < next_d) { next_d = best_d; next_id = best_id; }
@@ -800,6 +849,17 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   return 0;
 }
 
+// Register budget of the fast kernel: waves per SIMD the compiler must leave room for (gfx950: 512 VGPRs
+// per lane per SIMD -> 5 waves = 96 VGPRs).  Tuned on the bench workload; see DESIGN.md.
+#ifndef HS_WAVES_PER_EU
+#define HS_WAVES_PER_EU 0
+#endif
+#if HS_WAVES_PER_EU > 0
+#define HS_FAST_OCC __attribute__((amdgpu_waves_per_eu(HS_WAVES_PER_EU)))
+#else
+#define HS_FAST_OCC
+#endif
+
 // ---- kernels: grid-stride over the queries selected by status ----------------------------------------
 template <int METRIC>
 __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
@@ -817,7 +877,7 @@ __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
 // Fast kernel: a query whose k-subset hinges on a distance tie is answered right here by the strict path
 // (same workgroup, same LDS allocation -- the strict layout is a superset), marked pass 1 in the stats.
 template <int METRIC, int S, int D16>
-__global__ void __launch_bounds__(64) fast_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) HS_FAST_OCC fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
     if (!((1u << a.status[qi]) & a.select_mask)) continue;

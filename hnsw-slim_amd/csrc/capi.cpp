@@ -7,6 +7,9 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,15 +69,26 @@ struct hs_index {
   uint32_t user_cand_cap = 0, user_hash_slots = 0;
   uint32_t grow_cand = 0, grow_hash = 0;  // adaptive: doublings learnt from earlier batches' overflow counts
   bool exact_order = false;               // always use the strict kernel (reference output order)
-  size_t last_nq = 0;
   DevIndex dev{};
   DevBuf<float> vec;
   DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr, tile0;
   DevBuf<uint64_t> labels;
   DevBuf<uint8_t> deleted;
-  // per-call workspace (grow-only)
-  DevBuf<uint32_t> spill;  // visited-set tier 2, nq x kSpillSlots
-  DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, -}
+  // per-stream scratch (grow-only): calls on different HIP streams may be in flight together
+  struct StreamWs {
+    DevBuf<uint32_t> spill;             // visited-set tier 2, nq x kSpillSlots
+    DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, tier-2 spills}
+    size_t last_nq = 0;
+  };
+  std::map<hipStream_t, std::unique_ptr<StreamWs>> ws;
+  std::mutex ws_mu;
+  StreamWs *stream_ws(hipStream_t st) {
+    std::lock_guard<std::mutex> g(ws_mu);
+    auto &p = ws[st];
+    if (!p) p.reset(new StreamWs());
+    return p.get();
+  }
+  // host-pointer API staging (default stream)
   DevBuf<float> wq, wdist;
   DevBuf<uint32_t> wl32, wcnt, wstats, wrawsz;
   DevBuf<uint64_t> wl64;
@@ -88,16 +102,24 @@ static uint32_t next_pow2(uint32_t v) {
 }
 
 struct Shape {
-  uint32_t ef, cand_cap, hash_slots;
+  uint32_t ef, cand_cap, cand_cap_fast, hash_slots;
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
 static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
+static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
+static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap;  // words per query
 
 static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
   if (ef > (1u << 20)) return fail(HS_ERR_INVALID, "ef too large");
   s.ef = (uint32_t)ef;
+  // LDS share of the candidate heap: must cover essentially every query (peak heap size on the bench data:
+  // 2.4 ef median, 4.4 ef + 40 at p99.9) -- tier 2 is a safety net, a few %% of queries living in it already
+  // cost 15-40 %% of throughput (profiles/r01_tier2_cost.txt)
+  s.cand_cap_fast = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)(3 * ef + 256);
+  s.cand_cap_fast = (s.cand_cap_fast + 1) & ~1u;
+  // the strict kernel keeps its whole heap in LDS: cover the observed maximum (4.9 ef + margin)
   s.cand_cap = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((3 * ef + 256) << ix->grow_cand);
   s.cand_cap = (s.cand_cap + 1) & ~1u;
   // tier-1 visited set: sized so that most queries never leave LDS (75 % fill); the rest spill to tier 2
@@ -149,7 +171,6 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   }
   HIP_TRY(ix->labels.upload(p.labels));
   HIP_TRY(ix->deleted.upload(p.deleted));
-  HIP_TRY(ix->counters.alloc(12));
   DevIndex &d = ix->dev;
   d.vec = ix->vec.p; d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p;
   d.up_ptr = ix->up_ptr.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
@@ -240,30 +261,33 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   hs_status ps = plan_shape(ix, k, sh);
   if (ps != HS_OK) return ps;
   HIP_TRY(hipSetDevice(ix->device));
-  HIP_TRY(ix->status.ensure(nq));
-  HIP_TRY(ix->spill.ensure(nq * (size_t)kSpillSlots));
-  HIP_TRY(hipMemsetAsync(ix->status.p, 0, nq * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(ix->counters.p, 0, 12 * sizeof(uint32_t), stream));
-  ix->last_nq = nq;
+  hs_index::StreamWs *w = ix->stream_ws(stream);
+  HIP_TRY(w->status.ensure(nq));
+  HIP_TRY(w->spill.ensure(nq * (size_t)kSpillStride));
+  HIP_TRY(w->counters.ensure(12));
+  HIP_TRY(hipMemsetAsync(w->status.p, 0, nq * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
+  w->last_nq = nq;
   SearchArgs a{};
   a.queries = d_q; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.ef = sh.ef;
   a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.mode = mode;
   a.mark_ep = (ix->info.kind == HS_KIND_SLIM && mode == HS_MODE_PQ) ? 1 : 0;
   a.out_labels32 = l32; a.out_labels64 = l64; a.out_dists = dd; a.out_counts = cnt; a.stats = stats;
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
-  a.status = ix->status.p;
-  a.spill = ix->spill.p; a.spill_slots = kSpillSlots;
+  a.status = w->status.p;
+  a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
-                    fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap, sh.hash_slots) <= kLdsPerCU;
+                    fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, sh.hash_slots) <= kLdsPerCU;
+  if (fast) a.cand_cap = sh.cand_cap_fast;
   // pass 0: every query, one wavefront each
-  a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = ix->counters.p; a.pass_id = 0;
+  a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p; a.pass_id = 0;
   HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
   // (queries whose k-subset hinges on a distance tie are re-run inside the fast kernel by the strict path)
   // pass 2: queries that outgrew their scratch -> strict kernel with a whole CU's LDS each
   if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
     a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256);
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
-    a.counters = ix->counters.p + 8; a.pass_id = 2;
+    a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));
   }
   return HS_OK;
@@ -273,11 +297,13 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   if (!ix) return fail(HS_ERR_INVALID, "null index");
   uint32_t c[12];
   HIP_TRY(hipSetDevice(ix->device));
-  HIP_TRY(hipMemcpyAsync(c, ix->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  hs_index::StreamWs *w = ix->stream_ws((hipStream_t)stream);
+  if (!w->counters.p) return HS_OK;  // nothing was launched on this stream
+  HIP_TRY(hipMemcpyAsync(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   // learn the scratch sizes from the data: if more than 1% of a batch overflowed in the first passes,
   // later batches start with twice the visited-set slots / candidate capacity.
-  const size_t nq = std::max<size_t>(ix->last_nq, 1);
+  const size_t nq = std::max<size_t>(w->last_nq, 1);
   if ((size_t)c[3] * 10 > nq && ix->grow_hash < 8 && !ix->user_hash_slots) ix->grow_hash++;
   if ((size_t)(c[1] + c[5]) * 100 > nq && ix->grow_cand < 4 && !ix->user_cand_cap) ix->grow_cand++;
   if (c[8] + c[9] > 0)

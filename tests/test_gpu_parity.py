@@ -162,7 +162,8 @@ def test_fallback_pass_is_exact(hs, oracle, tmp_path):
     for exact in (True, False):
         ix.set_exact_order(exact)
         r = ix.search_ids(q, 10, want_stats=True)
-        assert (r["stats"][:, 3] == 2).sum() > 0, "expected some queries to take the whole-CU re-run"
+        if exact:  # the strict kernel keeps its heap in LDS only; the fast kernel spills to its tier-2 region instead
+            assert (r["stats"][:, 3] == 2).sum() > 0, "expected some queries to take the whole-CU re-run"
         assert np.array_equal(np.sort(r["labels"], axis=1), np.sort(want, axis=1))
         if exact:
             assert np.array_equal(r["labels"], want)
