@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path (hs_search_batch_dev: HierarchicalNSWSlim::searchKnn(q,k,tableint*)
 for every query) over one 10k-query batch that is already resident in HBM.  Workload = BASELINE.json
 configs[1]: SIFT-1M-like d=128 L2, M=16 efC=200, Slim defaults, k=10; ef_search = the smallest value of the
-sweep {32,...,256} whose recall@10 >= 0.95 on this data (all sweep points are reported in `config`).
+sweep {32,48,64,72,80,96,128,192,256} whose recall@10 >= 0.95 on this data (all sweep points are reported in `config`).
 
 Multi-GPU (torchrun, one rank per GPU): the index is replicated, every rank searches its own 10k-query
 batch (weak scaling) and the per-rank top-k labels are joined by one RCCL all-gather inside the step.
@@ -140,7 +140,7 @@ def main():
 
     # ---- ef sweep: recall + counters at every point; pick the operating point -----------------------
     sweep = {}
-    efs = [args.ef] if args.ef else [32, 64, 96, 128, 192, 256]
+    efs = [args.ef] if args.ef else [32, 48, 64, 72, 80, 96, 128, 192, 256]
     chosen = None
     for ef in efs:
         run(ef, stats=True)
@@ -252,6 +252,12 @@ def main():
                    serial_qps=round(ns / t1, 1), gpu_label_sets_identical=same)
 
     if rank == 0:
+        # HBM traffic from the PMC counters cannot be collected from inside this process; the committed
+        # profile (tools/traffic_cmd.sh -> profiles/r01_traffic.json) is quoted when it is for this workload.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and N == 1_000_000 and NQ == 10_000 and D == 128 and chosen == json.load(open(tpath)).get("ef"):
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         step_ms = elapsed / args.steps * 1e3
         achieved = alg_bytes_step / (step_ms * 1e-3) / 1e9          # timed region: S launches in flight
         achieved_single = alg_bytes_step / (kern_ms * 1e-3) / 1e9   # one launch alone on the GPU
@@ -265,7 +271,7 @@ def main():
                        "build_s": round(t_build, 1), "convert_s": round(t_conv, 1), "build_threads": threads,
                        "pipelining": f"steps issued round-robin on {S} HIP streams (up to {S} batches in flight)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms_effective": round(step_ms, 4), "launches_in_flight": S,
                          "single_launch_ms": round(kern_ms, 4), "single_launch_achieved": round(achieved_single, 1),
                          "single_launch_frac": round(achieved_single / HBM_PEAK_GBS, 4),

@@ -59,14 +59,18 @@ __host__ __device__ inline StrictLds strict_layout(uint32_t dim, uint32_t ef, ui
   l.total = l.off_nd + 64 * 4;
   return l;
 }
-// The fast path uses the same offsets (so a tie re-run by the strict path reuses the allocation); it
-// ignores the `top` area and stores heap element i at cand slot i+1 (room for that is the +2 below).
+// Fast path: no result array in LDS (it lives in registers); heap element i sits at cand slot i+1.  When a
+// tie has to be resolved the reference's result heap is rebuilt in the visited-set area, which is dead by then.
 struct FastLds { uint32_t off_q, off_cand, off_hash, off_nid, off_nd, total; };
 __host__ __device__ inline FastLds fast_layout(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
-  const StrictLds t = strict_layout(dim, ef, cand_cap + 2, hash_slots);
   FastLds l;
-  l.off_q = t.off_q; l.off_cand = t.off_cand; l.off_hash = t.off_hash; l.off_nid = t.off_nid; l.off_nd = t.off_nd;
-  l.total = t.total;
+  l.off_q = 0;
+  l.off_cand = align_up(dim * 4, 16);
+  l.off_hash = l.off_cand + align_up((cand_cap + 2) * 8, 16);
+  const uint32_t hash_bytes = hash_slots * 4 > (ef + 1) * 8 ? hash_slots * 4 : (ef + 1) * 8;
+  l.off_nid = l.off_hash + align_up(hash_bytes, 16);
+  l.off_nd = l.off_nid + 64 * 4;
+  l.total = l.off_nd + 64 * 4;
   return l;
 }
 size_t strict_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
@@ -688,6 +692,10 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   cand.L = a.cand_cap + 2;  // cand_cap is even
   cand.glob = reinterpret_cast<uint2 *>(a.spill + (size_t)qi * a.spill_stride + a.spill_slots);
   const uint32_t cand_total = a.spill ? a.cand_cap + a.cand2_cap : a.cand_cap;
+  // insertion log of the result set (the sequence of push_heap calls the reference makes, hnswalg_slim.h:418-423):
+  // 8 bytes per accepted neighbour, written by lane 0 and read back only if a tie must be resolved
+  uint2 *tlog = a.spill ? reinterpret_cast<uint2 *>(a.spill + (size_t)qi * a.spill_stride + a.spill_slots + 2 * a.cand2_cap) : nullptr;
+  uint32_t n_log = 0;
   uint32_t *hash = reinterpret_cast<uint32_t *>(smem + L.off_hash);
   uint32_t *nid = reinterpret_cast<uint32_t *>(smem + L.off_nid);
   float *nd = reinterpret_cast<float *>(smem + L.off_nd);
@@ -728,6 +736,8 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     lb = FLT_MAX;
   } else {
     top_insert<S>(tk, ti, top_size, ef, curdist, cur, lane);  // hnswalg_slim.h:2100-2101
+    if (tlog && lane == 0) tlog[0] = make_uint2(__float_as_uint(curdist), cur);
+    n_log = 1;
     lb = ep_deleted ? FLT_MAX : curdist;                       // :2104-2106
   }
   const uint32_t stride = ix.tile_stride;
@@ -800,7 +810,11 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         const uint32_t nb = __builtin_amdgcn_readlane(my_id, j);
         pending |= 1ull << j;
         if (!have_best || d < best_d) { best_d = d; best_id = nb; have_best = true; }
-        if (bare || uni(ix.deleted[nb]) == 0) top_insert<S>(tk, ti, top_size, ef, d, nb, lane);  // :418-448
+        if (bare || uni(ix.deleted[nb]) == 0) {
+          top_insert<S>(tk, ti, top_size, ef, d, nb, lane);  // :418-448
+          if (tlog && lane == 0 && n_log < a.log_cap) tlog[n_log] = make_uint2(__float_as_uint(d), nb);
+          n_log++;
+        }
         if (top_size > 0) lb = top_key_at<S>(tk, top_size - 1);  // :450-452
       }
     }
@@ -821,11 +835,58 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     return rc;
   }
   HS_T0_RESET();
-  // ---- k-selection: the k smallest distances; a tie across the k-th boundary makes the reference's
-  //      choice depend on its heap layout (nth_element / pop_heap) -> the strict path decides --------
+  // ---- k-selection: the k smallest distances.  A tie across the k-th boundary makes the reference's choice
+  //      depend on the LAYOUT of its result heap (nth_element / pop_heap pick among equal keys by position).
+  //      The traversal above is already the reference's, so its heap is rebuilt exactly by replaying the logged
+  //      insertions through libstdc++'s push_heap/pop_heap mechanics -- in the visited-set area, dead by now.
   if (top_size > k && top_key_at<S>(tk, k - 1) == top_key_at<S>(tk, k)) {
     if (lane == 0) atomicAdd(a.counters + 2, 1u);
-    return 3;
+    if (!tlog || n_log > a.log_cap) return 3;  // log did not fit: the strict kernel re-runs the query
+    Pair *top = reinterpret_cast<Pair *>(hash);
+    __threadfence_block();
+    uint32_t ts = 0;
+    for (uint32_t base = 0; base < n_log; base += 64) {
+      const uint32_t m = min(64u, n_log - base);
+      uint2 e = make_uint2(0, 0);
+      if ((uint32_t)lane < m) e = tlog[base + lane];
+      for (uint32_t j = 0; j < m; j++) {
+        const float d = __uint_as_float(__builtin_amdgcn_readlane(e.x, j));
+        const uint32_t nb = __builtin_amdgcn_readlane(e.y, j);
+        if (lane == 0) {
+          top[ts].d = d;  // hnswalg_slim.h:419-423
+          top[ts].id = nb;
+          push_heap(top, (long)ts + 1, LessD());
+          if (ts + 1 > ef) pop_heap(top, (long)ts + 1, LessD());  // :434-448
+        }
+        ts = min(ts + 1, ef);
+      }
+    }
+    if (lane == 0) {
+      if (a.mode == 0) {
+        nth_element(top, (long)k, (long)ts, LessD());  // hnswalg_slim.h:2126-2127
+      } else {
+        uint32_t t2 = ts;
+        while (t2 > k) { pop_heap(top, (long)t2, LessD()); t2--; }  // :2019-2022
+      }
+    }
+    wave_sync();
+    for (uint32_t i = lane; i < k; i += 64) {
+      const Pair p = top[i];
+      const uint64_t label = ix.labels[p.id];
+      if (a.out_labels32) a.out_labels32[(size_t)qi * k + i] = (uint32_t)label;
+      if (a.out_labels64) a.out_labels64[(size_t)qi * k + i] = label;
+      if (a.out_dists) a.out_dists[(size_t)qi * k + i] = p.d;
+    }
+    if (lane == 0) {
+      if (a.out_counts) a.out_counts[qi] = k;
+      HS_WALL(c);
+      Counters c1 = c;
+      SearchArgs a1 = a;
+      a1.pass_id = 1;  // answered by the tie replay
+      write_stats(a1, qi, c1);
+      a.status[qi] = ST_DONE;
+    }
+    return 0;
   }
   const uint32_t valid_n = min(top_size, k);
 #pragma unroll
@@ -874,8 +935,7 @@ __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
     wave_sync();
   }
 }
-// Fast kernel: a query whose k-subset hinges on a distance tie is answered right here by the strict path
-// (same workgroup, same LDS allocation -- the strict layout is a superset), marked pass 1 in the stats.
+// Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
 template <int METRIC, int S, int D16>
 __global__ void __launch_bounds__(64) HS_FAST_OCC fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -886,14 +946,8 @@ __global__ void __launch_bounds__(64) HS_FAST_OCC fast_kernel(DevIndex ix, Searc
       continue;
     }
     const int rc = search_one_fast<METRIC, S, D16>(ix, a, qi, smem);
+    if (rc == 3 && threadIdx.x == 0) a.status[qi] = ST_HAZARD;
     wave_sync();
-    if (rc == 3) {
-      SearchArgs b = a;
-      b.pass_id = 1;
-      b.cand_cap = a.cand_cap + 2;  // the allocation was laid out as strict_layout(dim, ef, cand_cap + 2, hash)
-      search_one_strict<METRIC>(ix, b, qi, smem);
-      wave_sync();
-    }
   }
 }
 

@@ -108,7 +108,8 @@ struct Shape {
 static constexpr size_t kLdsPerCU = 160 * 1024;
 static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
 static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
-static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap;  // words per query
+static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)
+static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap + 2 * kLogCap;  // words per query
 
 static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
@@ -117,7 +118,7 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   // LDS share of the candidate heap: must cover essentially every query (peak heap size on the bench data:
   // 2.4 ef median, 4.4 ef + 40 at p99.9) -- tier 2 is a safety net, a few %% of queries living in it already
   // cost 15-40 %% of throughput (profiles/r01_tier2_cost.txt)
-  s.cand_cap_fast = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)(3 * ef + 256);
+  s.cand_cap_fast = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)(4.4 * ef + 64);
   s.cand_cap_fast = (s.cand_cap_fast + 1) & ~1u;
   // the strict kernel keeps its whole heap in LDS: cover the observed maximum (4.9 ef + margin)
   s.cand_cap = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((3 * ef + 256) << ix->grow_cand);
@@ -275,14 +276,19 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   a.out_labels32 = l32; a.out_labels64 = l64; a.out_dists = dd; a.out_counts = cnt; a.stats = stats;
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
   a.status = w->status.p;
-  a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap;
+  a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
                     fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, sh.hash_slots) <= kLdsPerCU;
   if (fast) a.cand_cap = sh.cand_cap_fast;
   // pass 0: every query, one wavefront each
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p; a.pass_id = 0;
   HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
-  // (queries whose k-subset hinges on a distance tie are re-run inside the fast kernel by the strict path)
+  // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
+  if (fast) {
+    a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
+    a.counters = w->counters.p + 4; a.pass_id = 1;
+    HIP_TRY(launch_strict(ix->dev, a, stream));
+  }
   // pass 2: queries that outgrew their scratch -> strict kernel with a whole CU's LDS each
   if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
     a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256);

@@ -34,7 +34,7 @@ struct SearchArgs {
   uint32_t hash_slots;   // visited-set tier-1 (LDS) slots
   uint32_t *spill;       // per-query tier-2 region in global memory (nullable): [spill_slots u32 visited-set
                          // slots][cand2_cap x 8 B candidate-heap slots], spill_stride words apart
-  uint32_t spill_slots, spill_stride, cand2_cap;
+  uint32_t spill_slots, spill_stride, cand2_cap, log_cap;  // then log_cap x 8 B: result-set insertion log
   int32_t mode;          // hs_mode
   int32_t mark_ep;       // tag the enter point visited before the descent (slim (q,k) overloads)
   uint32_t select_mask;  // process query qi iff (1 << status[qi]) & select_mask
