@@ -490,7 +490,7 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
   // ---- level-0 (and threshold-level) beams ----------------------------------------------------
   const bool bare = !ix.has_deleted;  // hnswalg_slim.h:2114, hnswalg.h:1421 (no filter on this path)
   const bool ep_deleted = uni(ix.deleted[cur]) != 0;
-  if (ix.kind == 0) c.n_dist++;  // searchBaseLayerST recomputes the entry distance (hnswalg.h:351)
+  if (ix.kind == 0 && (bare || !ep_deleted)) c.n_dist++;  // searchBaseLayerST recomputes the entry distance (hnswalg.h:347-351)
   wave_sync();
   if (lane == 0) {
     vis_insert(vis, cur);  // visited_array[currObj] = tag (hnswalg_slim.h:2102)
@@ -713,7 +713,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
 
   const bool bare = !ix.has_deleted;
   const bool ep_deleted = uni(ix.deleted[cur]) != 0;
-  if (ix.kind == 0) c.n_dist++;  // hnswalg.h:351
+  if (ix.kind == 0 && (bare || !ep_deleted)) c.n_dist++;  // hnswalg.h:347-351
   float tk[S];
   uint32_t ti[S];
 #pragma unroll

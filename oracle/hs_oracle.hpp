@@ -309,9 +309,11 @@ struct Scratch {
 // Works on top/cand arrays exactly as the reference does (raw arrays + std::push_heap/pop_heap).
 template <class Index, class GetList0>
 inline void beam_level0(const Index &ix, const float *q, size_t ef, bool bare_bone, Scratch &s,
-                        float &lowerBound, Counters &c, GetList0 list0) {
-  s.cand.assign(s.top.begin(), s.top.end());                      // :327-329
-  std::make_heap(s.cand.begin(), s.cand.end(), cmp_min());        // :331-332
+                        float &lowerBound, Counters &c, GetList0 list0, bool seed_from_top = true) {
+  if (seed_from_top) {
+    s.cand.assign(s.top.begin(), s.top.end());                    // :327-329
+    std::make_heap(s.cand.begin(), s.cand.end(), cmp_min());      // :331-332
+  }
   while (!s.cand.empty()) {
     pairfi cur = s.cand.front();
     bool stop = bare_bone ? (cur.first > lowerBound)              // :340
@@ -506,9 +508,11 @@ inline SlimResult vanilla_search_pq(const VanillaIndex &ix, const float *q, size
     r.c.n_dist++;
     lowerBound = d;
     s.top.emplace_back(d, cur);
+    s.cand.assign(1, pairfi(d, cur));                        // :358
   } else {
-    // (:360-361) deleted entry point: candidate (-FLT_MAX, ep) with an empty result heap.
-    throw std::runtime_error("oracle: deleted entry point not restated for vanilla");
+    // (:360-361) deleted entry point: candidate (-FLT_MAX, ep) with an empty result heap
+    lowerBound = std::numeric_limits<float>::max();
+    s.cand.assign(1, pairfi(lowerBound, cur));
   }
   s.visited[cur] = s.tag;
   // candidate_set holds (-dist,id) in a max-heap by .first (:358, :432) == min-heap on dist with
@@ -516,7 +520,7 @@ inline SlimResult vanilla_search_pq(const VanillaIndex &ix, const float *q, size
   beam_level0(ix, q, ef, bare, s, lowerBound, r.c, [&](uint32_t id, const uint32_t *&ids, size_t &n) {
     ids = ix.list0(id, n);
     return true;
-  });
+  }, /*seed_from_top=*/false);
   r.top = s.top;
   std::vector<pairfi> t = r.top;
   while (t.size() > k) {                                     // :1430-1432

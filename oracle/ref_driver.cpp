@@ -117,11 +117,27 @@ static int cmd_search(int argc, char **argv) {
   return 0;
 }
 
+// markdel <metric> <dim> <index_in> <index_out> <every>
+// markDelete (hnswalg.h:923-1010) every `every`-th label, then saveIndex: an index file carrying delete marks,
+// which drives the !bare_bone_search branch of searchBaseLayerST (hnswalg.h:347-349, 441-444).
+static int cmd_markdel(int argc, char **argv) {
+  if (argc < 7) return 2;
+  auto *space = make_space(argv[2], atoi(argv[3]));
+  hnswlib::HierarchicalNSW<float> index(space, argv[4]);
+  size_t every = atoi(argv[6]);
+  size_t n = index.cur_element_count;
+  for (size_t l = every / 2; l < n; l += every) index.markDelete(l);
+  index.saveIndex(argv[5]);
+  printf("marked %zu deleted\n", (size_t)index.num_deleted_);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: ref_hnsw dist|build|search ...\n"); return 2; }
   std::string c = argv[1];
   if (c == "dist") return cmd_dist(argc, argv);
   if (c == "build") return cmd_build(argc, argv);
   if (c == "search") return cmd_search(argc, argv);
+  if (c == "markdel") return cmd_markdel(argc, argv);
   return 2;
 }

@@ -59,6 +59,23 @@ def index_fixture(tmp, name, metric, base, queries, M, efC, efs, k=10):
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **out)
 
 
+def deleted_fixture(tmp, src_name, metric, dim, every, efs, k=10):
+    """Same graph with delete marks (reference markDelete + saveIndex) and the reference's search results."""
+    src = os.path.join(GOLDEN, f"{src_name}.hnsw.bin")
+    dst = os.path.join(GOLDEN, f"{src_name}_del.hnsw.bin")
+    run("markdel", metric, dim, src, dst, every)
+    g = np.load(os.path.join(GOLDEN, f"{src_name}.npz"))
+    fq = os.path.join(tmp, "qd.fvecs")
+    write_fvecs(fq, g["queries"])
+    res = os.path.join(tmp, "resd.bin")
+    run("search", metric, dst, fq, res, k, *efs)
+    out = {"queries": g["queries"], "efs": np.array(efs), "k": np.array(k), "every": np.array(every)}
+    for ef, r in read_ref_search(res).items():
+        for key, v in r.items():
+            out[f"ef{ef}_{key}"] = v
+    np.savez_compressed(os.path.join(GOLDEN, f"{src_name}_del.npz"), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -75,6 +92,8 @@ def main():
         b /= np.linalg.norm(b, axis=1, keepdims=True)
         q /= np.linalg.norm(q, axis=1, keepdims=True)
         index_fixture(tmp, "ip_d48", "ip", b.astype(np.float32), q.astype(np.float32), 8, 100, [10, 48])
+        deleted_fixture(tmp, "l2_cont_d32", "l2", 32, 7, [10, 32, 64])
+        deleted_fixture(tmp, "l2_int_d16", "l2", 16, 5, [10, 48])
     print("golden fixtures written to", GOLDEN)
 
 

@@ -207,3 +207,43 @@ def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
     # closer-first order == reverse of the priority_queue pop order
     assert np.array_equal(rec["p"]["l"], w["labels"][:, ::-1])
     assert rec["p"]["d"].tobytes() == np.ascontiguousarray(w["dists"][:, ::-1]).tobytes()
+
+
+@pytest.mark.parametrize("name,dim", [("l2_cont_d32_del", 32), ("l2_int_d16_del", 16)])
+def test_delete_marks_vs_compiled_reference(hs, name, dim):
+    """Index saved by the reference after markDelete: both kernels take the !bare_bone_search branch."""
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    ix = hs.Index(os.path.join(GOLDEN, f"{name}.hnsw.bin"), hs.HS_KIND_HNSW, dim)
+    assert ix.info()["has_deleted"] == 1
+    k = int(g["k"])
+    for exact in (True, False):
+        ix.set_exact_order(exact)
+        for ef in g["efs"]:
+            ef = int(ef)
+            ix.set_ef(ef)
+            r = ix.search_pq(g["queries"], k, want_stats=True)
+            assert np.array_equal(r["cnt"], g[f"ef{ef}_cnt"])
+            assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(g[f"ef{ef}_dists"], g[f"ef{ef}_labels"], g[f"ef{ef}_cnt"])
+            assert np.array_equal(r["stats"][:, 0], g[f"ef{ef}_calls"])
+
+
+def test_tiny_and_degenerate_inputs(hs, oracle, tmp_path):
+    """n < k (priority_queue overload returns fewer than k), a single-element index, nq = 0."""
+    for n in (1, 7):
+        base = mixture(n, 16, 40 + n)
+        hp, sp = str(tmp_path / f"h{n}.bin"), str(tmp_path / f"s{n}.bin")
+        hs.build_hnsw(base, hp, M=4, ef_construction=10, threads=1)
+        hs.convert_slim(hp, sp, 16)
+        q = mixture(5, 16, 50)
+        for kind, path, okind in ((hs.HS_KIND_HNSW, hp, "hnsw"), (hs.HS_KIND_SLIM, sp, "slim")):
+            ix = hs.Index(path, kind, 16)
+            ox = oracle.load(path, okind, L2, 16)
+            ix.set_ef(10)
+            ox.set_ef(10)
+            r = ix.search_pq(q, 10)
+            o = ox.search_pq(q, 10)
+            assert np.array_equal(r["cnt"], o["cnt"]) and np.all(r["cnt"] == n)
+            assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(o["dists"], o["labels"], o["cnt"])
+            assert np.all(r["labels"][:, n:] == np.iinfo(np.uint64).max)
+            empty = ix.search_pq(q[:0], 10)
+            assert empty["labels"].shape == (0, 10)

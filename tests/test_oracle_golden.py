@@ -50,3 +50,21 @@ def test_load_errors(oracle, tmp_path):
     bad.write_bytes(data[: len(data) // 2])
     with pytest.raises(RuntimeError, match="corrupted"):
         oracle.load(str(bad), "hnsw", L2, 32)
+
+
+@pytest.mark.parametrize("name,dim", [("l2_cont_d32_del", 32), ("l2_int_d16_del", 16)])
+def test_vanilla_search_with_delete_marks_matches_reference(oracle, name, dim):
+    """Index saved by the reference after markDelete: the !bare_bone_search branch (hnswalg.h:347-349,441-444)."""
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    ix = oracle.load(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "hnsw", L2, dim)
+    k = int(g["k"])
+    every = int(g["every"])
+    for ef in g["efs"]:
+        ix.set_ef(int(ef))
+        r = ix.search_pq(g["queries"], k)
+        assert np.array_equal(r["cnt"], g[f"ef{ef}_cnt"])
+        assert np.array_equal(r["labels"], g[f"ef{ef}_labels"])
+        assert r["dists"].tobytes() == g[f"ef{ef}_dists"].tobytes()
+        assert np.array_equal(r["counters"][:, 0], g[f"ef{ef}_calls"])
+        valid = np.arange(k)[None, :] < r["cnt"][:, None]
+        assert not np.any((r["labels"][valid] % every) == every // 2), "a deleted label was returned"
