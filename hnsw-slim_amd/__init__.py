@@ -21,7 +21,7 @@ HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORT
 
 EXPORTS = [
     "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
-    "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw",
+    "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
     "hs_build_hnsw", "hs_convert_slim",
 ]
 
@@ -71,6 +71,8 @@ def lib():
     L.hs_search_batch_dev.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_search_check.argtypes = [vp, vp]
     L.hs_search_batch_raw.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp]
+    L.hs_search_batch_filtered.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.hs_labels.argtypes = [vp, vp]
     L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
     _lib = L
@@ -160,6 +162,24 @@ class Index:
         stats = np.empty((nq, 4), np.uint32) if want_stats else None
         _check(lib().hs_search_batch(self._h, q.ctypes.data, nq, k, HS_MODE_PQ, None, labels.ctypes.data, dists.ctypes.data,
                                      cnt.ctypes.data, stats.ctypes.data if want_stats else None))
+        return dict(labels=labels, dists=dists, cnt=cnt, stats=stats)
+
+    def labels(self):
+        out = np.empty(self.info()["n"], np.uint64)
+        _check(lib().hs_labels(self._h, out.ctypes.data))
+        return out
+
+    def search_filtered(self, queries, k, allowed, want_stats=False):
+        """searchKnn(q, k, isIdAllowed): allowed[i] != 0 iff the filter accepts the label of internal id i."""
+        q = np.ascontiguousarray(queries, np.float32)
+        a = np.ascontiguousarray(allowed, np.uint8)
+        nq = q.shape[0]
+        labels = np.empty((nq, k), np.uint64)
+        dists = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        stats = np.empty((nq, 4), np.uint32) if want_stats else None
+        _check(lib().hs_search_batch_filtered(self._h, q.ctypes.data, nq, k, a.ctypes.data, labels.ctypes.data, dists.ctypes.data,
+                                              cnt.ctypes.data, stats.ctypes.data if want_stats else None))
         return dict(labels=labels, dists=dists, cnt=cnt, stats=stats)
 
     def search_raw(self, queries, k, mode=HS_MODE_SLIM_IDS):

@@ -93,6 +93,9 @@ struct hs_index {
   DevBuf<uint32_t> wl32, wcnt, wstats, wrawsz;
   DevBuf<uint64_t> wl64;
   DevBuf<Pair> wraw;
+  std::vector<uint64_t> host_labels;   // external labels by internal id
+  std::vector<uint8_t> host_deleted;   // delete marks by internal id
+  DevBuf<uint8_t> wexcl;               // deleted | !allowed of the current filtered call
 };
 
 static uint32_t next_pow2(uint32_t v) {
@@ -172,6 +175,8 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   }
   HIP_TRY(ix->labels.upload(p.labels));
   HIP_TRY(ix->deleted.upload(p.deleted));
+  ix->host_labels = p.labels;
+  ix->host_deleted = p.deleted;
   DevIndex &d = ix->dev;
   d.vec = ix->vec.p; d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p;
   d.up_ptr = ix->up_ptr.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
@@ -380,6 +385,37 @@ hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t 
   if (mode == HS_MODE_PQ && (!out_labels64 || !out_dists || !out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
   return search_host(ix, queries, nq, k, mode, out_labels32, out_labels64, out_dists, out_counts, stats, nullptr,
                      nullptr, nullptr);
+}
+
+hs_status hs_labels(const hs_index *ix, uint64_t *out_labels) {
+  if (!ix || !out_labels) return fail(HS_ERR_INVALID, "null argument");
+  std::copy(ix->host_labels.begin(), ix->host_labels.end(), out_labels);
+  return HS_OK;
+}
+
+// The reference tests "!isMarkedDeleted(id) && (*isIdAllowed)(label)" together wherever a filter is consulted
+// (hnswalg.h:348-349, 442-444; hnswalg_slim.h:578-580), and a filter forces the !bare_bone branch
+// (hnswalg.h:1421, hnswalg_slim.h:1884).  So a filtered search is the ordinary search over an index whose
+// delete-mark array is (deleted | !allowed) and whose has_deleted flag is set.
+hs_status hs_search_batch_filtered(hs_index *ix, const float *queries, size_t nq, size_t k, const uint8_t *allowed,
+                                   uint64_t *out_labels64, float *out_dists, uint32_t *out_counts, uint32_t *stats) {
+  if (!ix || !allowed) return fail(HS_ERR_INVALID, "null argument");
+  if (!out_labels64 || !out_dists || !out_counts) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
+  if (ix->info.kind == HS_KIND_SLIM && ix->info.threshold_level != 0)
+    return fail(HS_ERR_UNSUPPORTED, "filtered search on a Slim index with threshold_level > 0 is not supported");
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t n = ix->info.n;
+  std::vector<uint8_t> excl(std::max<size_t>(n, 1));
+  for (size_t i = 0; i < n; i++) excl[i] = (ix->host_deleted[i] || !allowed[i]) ? 1 : 0;
+  HIP_TRY(ix->wexcl.ensure(excl.size()));
+  HIP_TRY(hipMemcpy(ix->wexcl.p, excl.data(), excl.size(), hipMemcpyHostToDevice));
+  const DevIndex saved = ix->dev;
+  ix->dev.deleted = ix->wexcl.p;
+  ix->dev.has_deleted = 1;
+  hs_status s = search_host(ix, queries, nq, k, HS_MODE_PQ, nullptr, out_labels64, out_dists, out_counts, stats, nullptr,
+                            nullptr, nullptr);
+  ix->dev = saved;
+  return s;
 }
 
 hs_status hs_search_batch_raw(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, float *raw_dists,

@@ -12,9 +12,10 @@
 //   space_l2.h:208-253       L2Space            space_ip.h:342-398  InnerProductSpace
 //   hnswalg.h:17-19,78-83,184,781,1378          HierarchicalNSW<float>
 //   hnswalg_slim.h:28-30,83-87,149-152,193,753,867,1907,2030   HierarchicalNSWSlim<float>
+// Filter functors are host callbacks: the facade evaluates one once per element into an allowed-array
+// (cached per functor object) and calls hs_search_batch_filtered.
 // Not provided (outside the search path): addPoint/updatePoint/markDelete, the diff/patch
-// protocol, stop conditions, and filter functors (host callbacks cannot run inside the kernel; passing a
-// non-null BaseFilterFunctor throws).
+// protocol, stop conditions.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -138,12 +139,26 @@ class DeviceIndex {
     check(hs_index_load(location.c_str(), kind, metric_, dim_, max_elements, device_, &h_));
     ef_ = 10;  // hnswalg.h:864, hnswalg_slim.h:793
   }
-  std::priority_queue<std::pair<float, labeltype>> search_pq(const void *q, size_t k) const {
+  mutable BaseFilterFunctor *cached_filter_ = nullptr;
+  mutable std::vector<uint8_t> allowed_;
+  std::priority_queue<std::pair<float, labeltype>> search_pq(const void *q, size_t k, BaseFilterFunctor *f = nullptr) const {
     std::priority_queue<std::pair<float, labeltype>> result;
     if (!h_) return result;
     std::vector<uint64_t> labels(k);
     std::vector<float> dists(k);
     uint32_t cnt = 0;
+    if (f) {
+      if (f != cached_filter_) {  // evaluate the functor once per element (hs_labels: label of each internal id)
+        hs_info info;
+        check(hs_index_info(h_, &info));
+        std::vector<uint64_t> all(info.n);
+        check(hs_labels(h_, all.data()));
+        allowed_.resize(info.n);
+        for (size_t i = 0; i < info.n; i++) allowed_[i] = (*f)((labeltype)all[i]) ? 1 : 0;
+        cached_filter_ = f;
+      }
+      check(hs_search_batch_filtered(h_, (const float *)q, 1, k, allowed_.data(), labels.data(), dists.data(), &cnt, nullptr));
+    } else
     check(hs_search_batch(h_, (const float *)q, 1, k, HS_MODE_PQ, nullptr, labels.data(), dists.data(), &cnt, nullptr));
     for (uint32_t i = 0; i < cnt; i++) result.emplace(dists[i], (labeltype)labels[i]);
     return result;
@@ -173,8 +188,7 @@ class HierarchicalNSW<float> : public AlgorithmInterface<float>, public detail::
   }
   std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k,
                                                              BaseFilterFunctor *isIdAllowed = nullptr) const override {
-    if (isIdAllowed) throw std::runtime_error("hnswlib_amd: filter functors are not supported on the GPU path");
-    return search_pq(query_data, k);
+    return search_pq(query_data, k, isIdAllowed);
   }
   // Batched searchKnn: nq x dim queries; out_labels / out_dists nq x k (unused slots: UINT64_MAX / +inf).
   void searchKnnBatch(const float *queries, size_t nq, size_t k, uint64_t *out_labels, float *out_dists,
@@ -216,8 +230,7 @@ class HierarchicalNSWSlim<float> : public AlgorithmInterface<float>, public deta
   // searchKnn(q, k, filter) / searchKnn(q, k): hnswalg_slim.h:1783-1905 / 1907-2028
   std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k,
                                                              BaseFilterFunctor *isIdAllowed = nullptr) const override {
-    if (isIdAllowed) throw std::runtime_error("hnswlib_amd: filter functors are not supported on the GPU path");
-    return search_pq(query_data, k);
+    return search_pq(query_data, k, isIdAllowed);
   }
   // searchKnn(q, k, tableint* result): hnswalg_slim.h:2030-2131.  k labels; same k-subset as the reference,
   // sorted by distance (call setExactOrder(true) to also reproduce the reference's array order).

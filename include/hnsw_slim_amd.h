@@ -96,6 +96,16 @@ hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t 
                           uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists,
                           uint32_t *out_counts, uint32_t *stats);
 
+/* searchKnn(q, k, BaseFilterFunctor* isIdAllowed): hnswalg.h:1378-1440 with :347-349,441-444, and
+ * hnswalg_slim.h:1783-1905 with :462-618.  The functor is a host callback, so the caller evaluates it once
+ * per element: allowed[i] != 0 iff (*isIdAllowed)(label of internal id i) (hs_labels() gives the labels).
+ * Always the priority_queue result shape (HS_MODE_PQ outputs).  Slim indexes: threshold_level == 0 only. */
+hs_status hs_search_batch_filtered(hs_index *ix, const float *queries, size_t nq, size_t k,
+                                   const uint8_t *allowed, uint64_t *out_labels64, float *out_dists,
+                                   uint32_t *out_counts, uint32_t *stats);
+/* External labels by internal id (n entries), to evaluate a filter functor on the host. */
+hs_status hs_labels(const hs_index *ix, uint64_t *out_labels);
+
 /* Same search with DEVICE pointers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
  * No host synchronisation happens here; call hs_search_check() after synchronising to learn whether
  * any query exhausted the fallback scratch. */

@@ -177,9 +177,13 @@ struct VanillaIndex {
     cnt = c;
     return (const uint32_t *)(p + 4);
   }
-  bool deleted(uint32_t i) const {  // hnswalg.h:~1000: byte 2 of the level-0 header & 1
+  // A filter (BaseFilterFunctor) is folded in as allowed[id]: the reference tests
+  // !isMarkedDeleted(id) && (*isIdAllowed)(label) together everywhere (hnswalg.h:348-349, 442-444).
+  std::vector<uint8_t> allowed;  // by internal id; empty = no filter
+  bool mark(uint32_t i) const {  // hnswalg.h:~1000: byte 2 of the level-0 header & 1
     return (level0[i * size_per_el + offsetLevel0 + 2] & 1) != 0;
   }
+  bool deleted(uint32_t i) const { return mark(i) || (!allowed.empty() && !allowed[i]); }
 
   void load(const std::string &path, Metric m, size_t dim_) {  // hnswalg.h:781-893
     Reader r(path);
@@ -213,7 +217,7 @@ struct VanillaIndex {
     }
     if (r.in.peek() != EOF) throw std::runtime_error("Index seems to be corrupted or unsupported");
     num_deleted = 0;
-    for (size_t i = 0; i < count; i++) num_deleted += deleted(i);
+    for (size_t i = 0; i < count; i++) num_deleted += mark(i);
   }
 };
 
@@ -235,7 +239,8 @@ struct SlimIndex {
   uint32_t total(uint32_t i) const { uint32_t v; memcpy(&v, el(i) + offsetTotal, 4); return v; }  // :644
   uint64_t label(uint32_t i) const { uint64_t v; memcpy(&v, el(i) + label_offset, 8); return v; } // :195
   const float *vec(uint32_t i) const { return (const float *)(el(i) + offsetData); }            // :208
-  bool deleted(uint32_t i) const { return (el(i)[4 + 2] & 1) != 0; }                            // :1776-1781
+  std::vector<uint8_t> allowed;  // filter by internal id (searchKnn(q,k,isIdAllowed), hnswalg_slim.h:1783-1905)
+  bool deleted(uint32_t i) const { return (el(i)[4 + 2] & 1) != 0 || (!allowed.empty() && !allowed[i]); }  // :1776-1781, :578-580
   // slice of node i at `lvl` (hnswalg_slim.h:2050-2062 / :363-369); false when the node has no blob
   bool slice(uint32_t i, int lvl, const uint32_t *&ids, size_t &n) const {
     if (blobs[i].empty()) return false;  // neighbors == nullptr (:2047, :360)
@@ -438,7 +443,7 @@ inline SlimResult slim_search_core(const SlimIndex &ix, const float *q, size_t k
   float lowerBound = !ix.deleted(cur) ? curdist : std::numeric_limits<float>::max();  // :2104-2106
   for (int lvl = std::min(ix.threshold_level, ix.maxlevel); lvl > 0; lvl--)            // :2108-2113
     slim_beam_layer(ix, q, lvl, ef, s, lowerBound, r.c);
-  bool bare = !ix.has_deleted;                               // :2114
+  bool bare = !ix.has_deleted && ix.allowed.empty();         // :2114, :1884
   beam_level0(ix, q, ef, bare, s, lowerBound, r.c,
               [&](uint32_t id, const uint32_t *&ids, size_t &n) { return ix.slice(id, 0, ids, n); });
   r.top = s.top;
@@ -499,7 +504,7 @@ inline SlimResult vanilla_search_pq(const VanillaIndex &ix, const float *q, size
     }
   }
   size_t ef = std::max(ix.ef, k);
-  bool bare = ix.num_deleted == 0;                           // :1421 (no filter)
+  bool bare = ix.num_deleted == 0 && ix.allowed.empty();     // :1421
   // searchBaseLayerST prologue (hnswalg.h:346-364): recomputes the entry distance.
   s.top.clear();
   float lowerBound;

@@ -27,6 +27,14 @@ void *hso_load(const char *path, int kind, int metric, size_t dim) {
 }
 void hso_free(void *p) { delete (Handle *)p; }
 void hso_set_ef(void *p, size_t ef) { auto *h = (Handle *)p; h->v.ef = ef; h->s.ef = ef; }
+// filter as an allowed[internal id] byte array (null = remove the filter)
+void hso_set_filter(void *p, const uint8_t *allowed) {
+  auto *h = (Handle *)p;
+  size_t n = h->kind == 0 ? h->v.count : h->s.count;
+  auto &dst = h->kind == 0 ? h->v.allowed : h->s.allowed;
+  if (allowed) dst.assign(allowed, allowed + n);
+  else dst.clear();
+}
 size_t hso_count(void *p) { auto *h = (Handle *)p; return h->kind == 0 ? h->v.count : h->s.count; }
 int hso_maxlevel(void *p) { auto *h = (Handle *)p; return h->kind == 0 ? h->v.maxlevel : h->s.maxlevel; }
 

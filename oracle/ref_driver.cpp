@@ -82,6 +82,14 @@ static int cmd_build(int argc, char **argv) {
   return 0;
 }
 
+// Filter used by `searchf`: allows every label with label % mod != rem  (BaseFilterFunctor, hnswlib.h:128-133).
+struct ModFilter : public hnswlib::BaseFilterFunctor {
+  size_t mod, rem;
+  ModFilter(size_t m, size_t r) : mod(m), rem(r) {}
+  bool operator()(hnswlib::labeltype id) override { return id % mod != rem; }
+};
+static ModFilter *g_filter = nullptr;
+
 // search <metric> <index> <query.fvecs> <out.bin> <k> <ef> [ef...]
 // out.bin: u32 nq, u32 k, u32 n_ef, then per ef: u32 ef, per query: u32 cnt, u32 n_dist_calls,
 //          cnt x {f32 dist, u64 label} in priority_queue pop order (farthest first).
@@ -103,7 +111,7 @@ static int cmd_search(int argc, char **argv) {
     o.write((char *)&ef, 4);
     for (size_t i = 0; i < nq; i++) {
       g_dist_calls = 0;
-      auto res = index.searchKnn(Q.data() + i * d, k);
+      auto res = index.searchKnn(Q.data() + i * d, k, g_filter);  // hnswalg.h:1378-1380
       uint32_t cnt = res.size(), calls = g_dist_calls;
       o.write((char *)&cnt, 4); o.write((char *)&calls, 4);
       while (!res.empty()) {
@@ -139,5 +147,12 @@ int main(int argc, char **argv) {
   if (c == "build") return cmd_build(argc, argv);
   if (c == "search") return cmd_search(argc, argv);
   if (c == "markdel") return cmd_markdel(argc, argv);
+  if (c == "searchf") {  // searchf <mod> <rem> <metric> <index> <query.fvecs> <out.bin> <k> <ef>...
+    if (argc < 10) return 2;
+    g_filter = new ModFilter(atoi(argv[2]), atoi(argv[3]));
+    std::vector<char *> a2 = {argv[0], argv[1]};
+    for (int i = 4; i < argc; i++) a2.push_back(argv[i]);
+    return cmd_search((int)a2.size(), a2.data());
+  }
   return 2;
 }

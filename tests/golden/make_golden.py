@@ -76,6 +76,21 @@ def deleted_fixture(tmp, src_name, metric, dim, every, efs, k=10):
     np.savez_compressed(os.path.join(GOLDEN, f"{src_name}_del.npz"), **out)
 
 
+def filter_fixture(tmp, src_name, metric, mod, rem, efs, k=10):
+    """searchKnn(q, k, isIdAllowed) of the reference with the filter label % mod != rem."""
+    src = os.path.join(GOLDEN, f"{src_name}.hnsw.bin")
+    g = np.load(os.path.join(GOLDEN, f"{src_name.replace('_del', '')}.npz"))
+    fq = os.path.join(tmp, "qf.fvecs")
+    write_fvecs(fq, g["queries"])
+    res = os.path.join(tmp, "resf.bin")
+    run("searchf", mod, rem, metric, src, fq, res, k, *efs)
+    out = {"queries": g["queries"], "efs": np.array(efs), "k": np.array(k), "mod": np.array(mod), "rem": np.array(rem)}
+    for ef, r in read_ref_search(res).items():
+        for key, v in r.items():
+            out[f"ef{ef}_{key}"] = v
+    np.savez_compressed(os.path.join(GOLDEN, f"{src_name}_filter.npz"), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -94,6 +109,8 @@ def main():
         index_fixture(tmp, "ip_d48", "ip", b.astype(np.float32), q.astype(np.float32), 8, 100, [10, 48])
         deleted_fixture(tmp, "l2_cont_d32", "l2", 32, 7, [10, 32, 64])
         deleted_fixture(tmp, "l2_int_d16", "l2", 16, 5, [10, 48])
+        filter_fixture(tmp, "l2_cont_d32", "l2", 3, 1, [10, 32, 64])
+        filter_fixture(tmp, "l2_int_d16_del", "l2", 4, 0, [10, 48])   # delete marks AND a filter
     print("golden fixtures written to", GOLDEN)
 
 

@@ -100,6 +100,7 @@ class Oracle:
         L.hso_load.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
         L.hso_free.argtypes = [ctypes.c_void_p]
         L.hso_set_ef.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.hso_set_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.hso_count.restype = ctypes.c_size_t
         L.hso_count.argtypes = [ctypes.c_void_p]
         L.hso_maxlevel.argtypes = [ctypes.c_void_p]
@@ -154,6 +155,15 @@ class OracleIndex:
     def set_ef(self, ef):
         self.ef = ef
         self.o.L.hso_set_ef(self.h, ef)
+
+    def set_filter(self, allowed):
+        """allowed: uint8[n] by internal id, or None."""
+        if allowed is None:
+            self.o.L.hso_set_filter(self.h, None)
+        else:
+            a = np.ascontiguousarray(allowed, np.uint8)
+            assert a.shape[0] == self.count
+            self.o.L.hso_set_filter(self.h, a.ctypes.data)
 
     def search_ids(self, q, k, threads=1, raw=True):
         """HierarchicalNSWSlim::searchKnn(q,k,tableint*) -> dict(labels, raw_d, raw_i, raw_sz, counters)."""

@@ -247,3 +247,34 @@ def test_tiny_and_degenerate_inputs(hs, oracle, tmp_path):
             assert np.all(r["labels"][:, n:] == np.iinfo(np.uint64).max)
             empty = ix.search_pq(q[:0], 10)
             assert empty["labels"].shape == (0, 10)
+
+
+@pytest.mark.parametrize("name,dim", [("l2_cont_d32", 32), ("l2_int_d16_del", 16)])
+def test_filtered_search_vs_compiled_reference(hs, oracle, tmp_path, name, dim):
+    """searchKnn(q, k, isIdAllowed): vanilla index against the compiled reference's output; the Slim
+    conversion of the same graph against the oracle's restatement of hnswalg_slim.h:1783-1905."""
+    g = np.load(os.path.join(GOLDEN, f"{name}_filter.npz"))
+    hp = os.path.join(GOLDEN, f"{name}.hnsw.bin")
+    ix = hs.Index(hp, hs.HS_KIND_HNSW, dim)
+    allowed = (ix.labels() % int(g["mod"]) != int(g["rem"])).astype(np.uint8)
+    k = int(g["k"])
+    for ef in g["efs"]:
+        ef = int(ef)
+        ix.set_ef(ef)
+        r = ix.search_filtered(g["queries"], k, allowed, want_stats=True)
+        assert np.array_equal(r["cnt"], g[f"ef{ef}_cnt"])
+        assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(g[f"ef{ef}_dists"], g[f"ef{ef}_labels"], g[f"ef{ef}_cnt"])
+        assert np.array_equal(r["stats"][:, 0], g[f"ef{ef}_calls"])
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(hp, sp, dim)
+    sx = hs.Index(sp, hs.HS_KIND_SLIM, dim)
+    ox = oracle.load(sp, "slim", L2, dim)
+    ox.set_filter(allowed)
+    for ef in (10, 40):
+        sx.set_ef(ef)
+        ox.set_ef(ef)
+        r = sx.search_filtered(g["queries"], k, allowed, want_stats=True)
+        o = ox.search_pq(g["queries"], k)
+        assert np.array_equal(r["cnt"], o["cnt"])
+        assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(o["dists"], o["labels"], o["cnt"])
+        assert np.array_equal(r["stats"][:, :3], o["counters"][:, :3])

@@ -68,3 +68,20 @@ def test_vanilla_search_with_delete_marks_matches_reference(oracle, name, dim):
         assert np.array_equal(r["counters"][:, 0], g[f"ef{ef}_calls"])
         valid = np.arange(k)[None, :] < r["cnt"][:, None]
         assert not np.any((r["labels"][valid] % every) == every // 2), "a deleted label was returned"
+
+
+@pytest.mark.parametrize("name,dim", [("l2_cont_d32", 32), ("l2_int_d16_del", 16)])
+def test_vanilla_filtered_search_matches_reference(oracle, name, dim):
+    """searchKnn(q, k, isIdAllowed) of the compiled reference (filter: label % mod != rem)."""
+    g = np.load(os.path.join(GOLDEN, f"{name}_filter.npz"))
+    ix = oracle.load(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "hnsw", L2, dim)
+    labels = np.arange(ix.count)  # golden indexes are built with label == internal id
+    ix.set_filter((labels % int(g["mod"]) != int(g["rem"])).astype(np.uint8))
+    k = int(g["k"])
+    for ef in g["efs"]:
+        ix.set_ef(int(ef))
+        r = ix.search_pq(g["queries"], k)
+        assert np.array_equal(r["cnt"], g[f"ef{ef}_cnt"])
+        assert np.array_equal(r["labels"], g[f"ef{ef}_labels"])
+        assert r["dists"].tobytes() == g[f"ef{ef}_dists"].tobytes()
+        assert np.array_equal(r["counters"][:, 0], g[f"ef{ef}_calls"])
