@@ -54,9 +54,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--base-size", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--batch", dest="nq", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=0, help="fixed ef_search (0 = smallest sweep value with recall>=0.95)")
     ap.add_argument("--build-threads", type=int, default=0)
@@ -74,10 +74,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (1-GPU box): HS_BENCH_ONE_DEVICE=1 maps every rank to cuda:0, HS_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the driver's multi-GPU run uses neither.
+    if os.environ.get("HS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("HS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     hs = load_product()
