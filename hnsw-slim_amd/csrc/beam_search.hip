@@ -106,6 +106,22 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
 
+// Minimum of v over the wave without touching LDS: inclusive min-scan inside each row of 16 lanes with DPP
+// row_shr, then the four row results (lanes 15/31/47/63) are combined through SGPRs.
+__device__ __forceinline__ float wave_min_f32(float v) {
+  const uint32_t inf = __float_as_uint(FLT_MAX);
+#define HS_SHR_MIN(ctrl) v = fminf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)__float_as_uint(v), ctrl, 0xf, 0xf, false)))
+  HS_SHR_MIN(0x111);  // row_shr:1
+  HS_SHR_MIN(0x112);  // row_shr:2
+  HS_SHR_MIN(0x114);  // row_shr:4
+  HS_SHR_MIN(0x118);  // row_shr:8
+#undef HS_SHR_MIN
+  const uint32_t b = __float_as_uint(v);
+  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __uint_as_float(__builtin_amdgcn_readlane(b, 31));
+  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __uint_as_float(__builtin_amdgcn_readlane(b, 63));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
 struct Counters {
   uint32_t n_dist, n_hops, n_nbr;
 #ifdef HS_PROFILE
@@ -328,16 +344,9 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
         c.n_nbr += m;
         c.n_dist += m;
         // first index attaining the minimum == what the sequential `if (d < curdist)` scan ends on
-        float d = (uint32_t)lane < m ? nd[lane] : FLT_MAX;
-        uint32_t l = lane;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const float od = __shfl_xor(d, off, 64);
-          const uint32_t ol = __shfl_xor(l, off, 64);
-          if (od < d || (od == d && ol < l)) { d = od; l = ol; }
-        }
-        d = unif(d);  // every lane holds the same (d, l): tell the compiler so the branch below is scalar
-        l = uni(l);
+        const float mine = (uint32_t)lane < m ? nd[lane] : FLT_MAX;
+        const float d = wave_min_f32(mine);
+        const uint32_t l = (uint32_t)__ffsll((long long)__ballot((uint32_t)lane < m && mine == d)) - 1;
         if (l < m && d < curdist) {  // hnswalg_slim.h:2071-2075
           curdist = d;
           cur = uni(nid[l]);
@@ -910,17 +919,6 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   return 0;
 }
 
-// Register budget of the fast kernel: waves per SIMD the compiler must leave room for (gfx950: 512 VGPRs
-// per lane per SIMD -> 5 waves = 96 VGPRs).  Tuned on the bench workload; see DESIGN.md.
-#ifndef HS_WAVES_PER_EU
-#define HS_WAVES_PER_EU 0
-#endif
-#if HS_WAVES_PER_EU > 0
-#define HS_FAST_OCC __attribute__((amdgpu_waves_per_eu(HS_WAVES_PER_EU)))
-#else
-#define HS_FAST_OCC
-#endif
-
 // ---- kernels: grid-stride over the queries selected by status ----------------------------------------
 template <int METRIC>
 __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
@@ -937,7 +935,7 @@ __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
 template <int METRIC, int S, int D16>
-__global__ void __launch_bounds__(64) HS_FAST_OCC fast_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
     if (!((1u << a.status[qi]) & a.select_mask)) continue;
