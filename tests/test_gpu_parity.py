@@ -278,3 +278,26 @@ def test_filtered_search_vs_compiled_reference(hs, oracle, tmp_path, name, dim):
         assert np.array_equal(r["cnt"], o["cnt"])
         assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(o["dists"], o["labels"], o["cnt"])
         assert np.array_equal(r["stats"][:, :3], o["counters"][:, :3])
+
+
+def test_wide_graphs_large_ef_large_k(hs, oracle, tmp_path):
+    """M=32 (level-0 tiles of 64 ids), M=40 (degree 80: no tile, strict kernel answers), ef up to 400
+    (8 result slots per lane), k=100."""
+    base = mixture(5000, 32, 61, integer=True)
+    q = mixture(100, 32, 62, integer=True)
+    _slim_case(hs, oracle, tmp_path, base, q, 32, L2, 32, 100, [400], k=100, low_degree_m0=24)
+    ix = hs.Index(str(tmp_path / "s.bin"), hs.HS_KIND_SLIM, 32)
+    assert 32 < ix.info()["max_degree0"] <= 64
+    # vanilla index with degree up to 80 (> 64): both modes fall back to the CSR path of the strict kernel
+    hp = str(tmp_path / "h40.bin")
+    hs.build_hnsw(base, hp, M=40, ef_construction=100, threads=8)
+    vx = hs.Index(hp, hs.HS_KIND_HNSW, 32)
+    assert vx.info()["max_degree0"] > 64
+    ov = oracle.load(hp, "hnsw", L2, 32)
+    for ef in (20, 150):
+        vx.set_ef(ef)
+        ov.set_ef(ef)
+        r = vx.search_pq(q, 10, want_stats=True)
+        o = ov.search_pq(q, 10)
+        assert _pq_sorted(r["dists"], r["labels"], r["cnt"]) == _pq_sorted(o["dists"], o["labels"], o["cnt"])
+        assert np.array_equal(r["stats"][:, :3], o["counters"][:, :3])
