@@ -22,7 +22,8 @@ HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORT
 EXPORTS = [
     "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
-    "hs_build_hnsw", "hs_convert_slim",
+    "hs_build_hnsw", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
+    "hs_rabitq_estimate",
 ]
 
 
@@ -75,6 +76,10 @@ def lib():
     L.hs_labels.argtypes = [vp, vp]
     L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
+    L.hs_rabitq_rotate.argtypes = [sz, vp, vp, sz, vp]
+    L.hs_rabitq_quantize_data.argtypes = [sz, ci, vp, sz, vp, vp, vp]
+    L.hs_rabitq_prepare_query.argtypes = [sz, ctypes.c_double, vp, sz, vp, vp]
+    L.hs_rabitq_estimate.argtypes = [sz, vp, vp, sz, vp, vp, vp, vp, sz, vp]
     _lib = L
     return L
 
@@ -100,6 +105,44 @@ def convert_slim(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=
     """HierarchicalNSWSlim::convertFromHNSW + saveIndex, on the CPU (harness)."""
     _check(lib().hs_convert_slim(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
                                  top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
+
+
+def rabitq_rotate(dim, flips, x):
+    x = np.ascontiguousarray(x, np.float32)
+    padded = (dim + 63) // 64 * 64
+    flips = np.ascontiguousarray(flips, np.uint8)
+    out = np.empty((x.shape[0], padded), np.float32)
+    _check(lib().hs_rabitq_rotate(dim, flips.ctypes.data, x.ctypes.data, x.shape[0], out.ctypes.data))
+    return out
+
+
+def rabitq_quantize_data(rotated, centroid, metric=HS_METRIC_L2):
+    r = np.ascontiguousarray(rotated, np.float32)
+    c = np.ascontiguousarray(centroid, np.float32)
+    n, padded = r.shape
+    codes = np.empty((n, padded // 64), np.uint64)
+    fac = np.empty((n, 3), np.float32)
+    _check(lib().hs_rabitq_quantize_data(padded, metric, r.ctypes.data, n, c.ctypes.data, codes.ctypes.data, fac.ctypes.data))
+    return codes, fac
+
+
+def rabitq_prepare_query(rotated_q, t_const):
+    r = np.ascontiguousarray(rotated_q, np.float32)
+    n, padded = r.shape
+    q3 = np.empty((n, 3), np.float32)
+    bins = np.empty((n, padded // 64 * 4), np.uint64)
+    _check(lib().hs_rabitq_prepare_query(padded, float(t_const), r.ctypes.data, n, q3.ctypes.data, bins.ctypes.data))
+    return q3, bins
+
+
+def rabitq_estimate(codes, fac, q3, bins, g_add, g_error):
+    nd, nblk = codes.shape
+    nq = q3.shape[0]
+    out = np.empty((nq, nd, 3), np.float32)
+    a = [np.ascontiguousarray(x) for x in (codes, fac, q3, bins, np.asarray(g_add, np.float32), np.asarray(g_error, np.float32))]
+    _check(lib().hs_rabitq_estimate(nblk * 64, a[0].ctypes.data, a[1].ctypes.data, nd, a[2].ctypes.data, a[3].ctypes.data,
+                                    a[4].ctypes.data, a[5].ctypes.data, nq, out.ctypes.data))
+    return out
 
 
 class Index:

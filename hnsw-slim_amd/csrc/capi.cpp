@@ -16,6 +16,8 @@
 #include "../../include/hnsw_slim_amd.h"
 #include "engine.hpp"
 #include "host_graph.hpp"
+#include "rabitq_est.hpp"
+#include "rabitq_host.hpp"
 
 using namespace hs;
 
@@ -458,6 +460,46 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
   } catch (std::exception &e) {
     return from_exception(e);
   }
+  return HS_OK;
+}
+
+hs_status hs_rabitq_rotate(size_t dim, const uint8_t *flips, const float *in, size_t n, float *out) {
+  if (!flips || !in || !out || dim == 0) return fail(HS_ERR_INVALID, "bad argument");
+  Rotator r;
+  r.init(dim);
+  if (r.trunc < 64 || r.trunc > 2048) return fail(HS_ERR_UNSUPPORTED, "rotator supports 64 <= dim < 4096");
+  std::copy(flips, flips + r.flip.size(), r.flip.begin());
+  for (size_t i = 0; i < n; i++) r.rotate(in + i * dim, out + i * r.padded);
+  return HS_OK;
+}
+hs_status hs_rabitq_quantize_data(size_t padded, int metric, const float *rotated, size_t n, const float *centroid,
+                                  uint64_t *codes, float *factors) {
+  if (!rotated || !centroid || !codes || !factors || padded % 64) return fail(HS_ERR_INVALID, "bad argument");
+  for (size_t i = 0; i < n; i++) rq_quantize_data(rotated + i * padded, centroid, padded, metric, codes + i * padded / 64, factors + i * 3);
+  return HS_OK;
+}
+hs_status hs_rabitq_prepare_query(size_t padded, double t_const, const float *rotated_q, size_t n, float *out3,
+                                  uint64_t *bins) {
+  if (!rotated_q || !out3 || !bins || padded % 64) return fail(HS_ERR_INVALID, "bad argument");
+  RqQuery q;
+  for (size_t i = 0; i < n; i++) {
+    rq_prepare_query(rotated_q + i * padded, padded, t_const, q);
+    out3[i * 3] = q.delta; out3[i * 3 + 1] = q.vl; out3[i * 3 + 2] = q.k1xsumq;
+    std::copy(q.bins.begin(), q.bins.end(), bins + i * padded / 64 * 4);
+  }
+  return HS_OK;
+}
+hs_status hs_rabitq_estimate(size_t padded, const uint64_t *codes, const float *factors, size_t nd, const float *q3,
+                             const uint64_t *bins, const float *g_add, const float *g_error, size_t nq, float *out) {
+  if (!codes || !factors || !q3 || !bins || !g_add || !g_error || !out) return fail(HS_ERR_INVALID, "bad argument");
+  const uint32_t nblk = (uint32_t)(padded / 64);
+  for (size_t i = 0; i < nq; i++)
+    for (size_t j = 0; j < nd; j++) {
+      const float ip = rq_ip_x0_qr(codes + j * nblk, bins + i * nblk * 4, nblk, q3[i * 3], q3[i * 3 + 1]);
+      const float est = rq_est_dist(factors[j * 3], g_add[i], factors[j * 3 + 1], ip, q3[i * 3 + 2]);
+      float *o = out + (i * nd + j) * 3;
+      o[0] = ip; o[1] = est; o[2] = est - factors[j * 3 + 2] * g_error[i];
+    }
   return HS_OK;
 }
 

@@ -131,6 +131,21 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
                           size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int threads,
                           const char *out_path);
 
+/* ---- RaBitQ pieces of the HNSW-SlimQ path (CPU; used by the SlimQ harness and query preparation, exposed
+ *      so that tests can pin them against the compiled rabitqlib) ------------------------------------- */
+/* FhtKacRotator::rotate: rabitqlib/utils/rotator.hpp:370-423.  flips = 4*padded/8 bytes, out = n x padded. */
+hs_status hs_rabitq_rotate(size_t dim, const uint8_t *flips, const float *in, size_t n, float *out);
+/* one_bit_compact_code<float,uint64_t>: rabitqlib/quantization/rabitq_impl.hpp:75-187.  codes n x padded/64,
+ * factors n x {f_add, f_rescale, f_error}. */
+hs_status hs_rabitq_quantize_data(size_t padded, int metric, const float *rotated, size_t n, const float *centroid,
+                                  uint64_t *codes, float *factors);
+/* SplitSingleQuery ctor: rabitqlib/index/query.hpp:112-156.  out3 n x {delta, vl, k1xsumq}; bins n x padded/64*4. */
+hs_status hs_rabitq_prepare_query(size_t padded, double t_const, const float *rotated_q, size_t n, float *out3,
+                                  uint64_t *bins);
+/* split_single_estdist: rabitqlib/index/estimator.hpp:164-188.  out nq x nd x {ip_x0_qr, est_dist, low_dist}. */
+hs_status hs_rabitq_estimate(size_t padded, const uint64_t *codes, const float *factors, size_t nd, const float *q3,
+                             const uint64_t *bins, const float *g_add, const float *g_error, size_t nq, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+// oracle/ref_rabitq.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Driver around the *unmodified* vendored rabitqlib (/root/reference/third_party/rabitqlib, with the vendored
+// Eigen), compiled by oracle/Makefile from the sources where they lie.  It pins the pieces of the HNSW-SlimQ
+// search path that are separable from hnswalg_slimq.h (which itself needs folly and is unbuildable here):
+//   rotate : FhtKacRotator::rotate                     rabitqlib/utils/rotator.hpp:370-423
+//   query  : SplitSingleQuery ctor (4-bit scalar quantisation + bit-plane transpose)
+//                                                        rabitqlib/index/query.hpp:112-156
+//            + split_single_estdist / warmup_ip_x0_q     rabitqlib/index/estimator.hpp:164-188,
+//                                                        rabitqlib/utils/warmup_space.hpp:8-102
+//   data   : one_bit_compact_code (1-bit code + f_add, f_rescale, f_error)
+//                                                        rabitqlib/quantization/rabitq_impl.hpp:75-187
+// All arrays are raw little-endian binaries; shapes are passed on the command line (tests/golden/make_golden.py).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "rabitqlib/index/estimator.hpp"
+#include "rabitqlib/index/query.hpp"
+#include "rabitqlib/quantization/rabitq.hpp"
+#include "rabitqlib/utils/rotator.hpp"
+
+template <typename T>
+static std::vector<T> rd(const char *p, size_t n) {
+  std::vector<T> v(n);
+  std::ifstream in(p, std::ios::binary);
+  in.read((char *)v.data(), n * sizeof(T));
+  if (!in) { fprintf(stderr, "short read %s\n", p); exit(2); }
+  return v;
+}
+template <typename T>
+static void wr(const char *p, const std::vector<T> &v) {
+  std::ofstream o(p, std::ios::binary);
+  o.write((const char *)v.data(), v.size() * sizeof(T));
+}
+
+int main(int argc, char **argv) {
+  std::string c = argc > 1 ? argv[1] : "";
+  if (c == "rotate") {  // rotate <dim> <flip.bin> <in.f32> <n> <out.f32>   (flip.bin is created if missing)
+    size_t dim = atoi(argv[2]), n = atoi(argv[5]);
+    size_t padded = rabitqlib::round_up_to_multiple(dim, 64);
+    auto *rot = rabitqlib::choose_rotator<float>(dim, rabitqlib::RotatorType::FhtKacRotator, padded);
+    {
+      std::ifstream f(argv[3], std::ios::binary);
+      if (f.good()) rot->load(f);
+      else { std::ofstream o(argv[3], std::ios::binary); rot->save(o); }
+    }
+    auto in = rd<float>(argv[4], n * dim);
+    std::vector<float> out(n * padded);
+    for (size_t i = 0; i < n; i++) rot->rotate(in.data() + i * dim, out.data() + i * padded);
+    wr(argv[6], out);
+    return 0;
+  }
+  if (c == "data") {  // data <padded> <metric 0=L2 1=IP> <rot.f32> <n> <centroid.f32> <codes.u64> <factors.f32>
+    size_t padded = atoi(argv[2]), n = atoi(argv[5]);
+    auto metric = atoi(argv[3]) ? rabitqlib::METRIC_IP : rabitqlib::METRIC_L2;
+    auto x = rd<float>(argv[4], n * padded);
+    auto cen = rd<float>(argv[6], padded);
+    std::vector<uint64_t> codes(n * padded / 64);
+    std::vector<float> fac(n * 3);
+    for (size_t i = 0; i < n; i++)
+      rabitqlib::quant::rabitq_impl::one_bit::one_bit_compact_code<float, uint64_t>(
+          x.data() + i * padded, cen.data(), padded, codes.data() + i * padded / 64, fac[i * 3], fac[i * 3 + 1], fac[i * 3 + 2], metric);
+    wr(argv[7], codes);
+    wr(argv[8], fac);
+    return 0;
+  }
+  if (c == "query") {
+    // query <padded> <metric> <t_const> <rotq.f32> <nq> <codes.u64> <factors.f32> <nd> <gadd.f32 nq> <gerr.f32 nq>
+    //       <out_q.f32: nq x 3 {delta, vl, k1xsumq}> <out_bins.u64: nq x padded/64*4> <out_est.f32: nq x nd x 3>
+    size_t padded = atoi(argv[2]), nq = atoi(argv[6]), nd = atoi(argv[9]);
+    size_t metric = atoi(argv[3]) ? rabitqlib::METRIC_IP : rabitqlib::METRIC_L2;
+    rabitqlib::quant::RabitqConfig cfg;
+    cfg.t_const = atof(argv[4]);
+    auto q = rd<float>(argv[5], nq * padded);
+    auto codes = rd<uint64_t>(argv[7], nd * padded / 64);
+    auto fac = rd<float>(argv[8], nd * 3);
+    auto gadd = rd<float>(argv[10], nq), gerr = rd<float>(argv[11], nq);
+    const size_t rec = padded / 8 + 12;
+    std::vector<char> bin(nd * rec);  // ConstBinDataMap layout: code bytes, then f_add, f_rescale, f_error
+    for (size_t j = 0; j < nd; j++) {
+      memcpy(bin.data() + j * rec, codes.data() + j * padded / 64, padded / 8);
+      memcpy(bin.data() + j * rec + padded / 8, fac.data() + j * 3, 12);
+    }
+    std::vector<float> oq(nq * 3), oe(nq * nd * 3);
+    std::vector<uint64_t> ob(nq * padded / 64 * 4);
+    for (size_t i = 0; i < nq; i++) {
+      rabitqlib::SplitSingleQuery<float> w(q.data() + i * padded, padded, 3, cfg, metric);
+      oq[i * 3] = w.delta(); oq[i * 3 + 1] = w.vl(); oq[i * 3 + 2] = w.k1xsumq();
+      memcpy(ob.data() + i * padded / 64 * 4, w.query_bin(), padded / 64 * 4 * 8);
+      for (size_t j = 0; j < nd; j++) {
+        float ip, est, low;
+        rabitqlib::split_single_estdist(bin.data() + j * rec, w, padded, ip, est, low, gadd[i], gerr[i]);
+        oe[(i * nd + j) * 3] = ip; oe[(i * nd + j) * 3 + 1] = est; oe[(i * nd + j) * 3 + 2] = low;
+      }
+    }
+    wr(argv[12], oq); wr(argv[13], ob); wr(argv[14], oe);
+    return 0;
+  }
+  if (c == "tconst") {  // tconst <padded> : one draw of faster_config(padded, 4).t_const (random, rabitq.hpp:27-34)
+    auto cfg = rabitqlib::quant::faster_config(atoi(argv[2]), 4);
+    printf("%.17g\n", cfg.t_const);
+    return 0;
+  }
+  fprintf(stderr, "usage: ref_rabitq rotate|data|query|tconst ...\n");
+  return 2;
+}

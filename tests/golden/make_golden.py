@@ -91,6 +91,42 @@ def filter_fixture(tmp, src_name, metric, mod, rem, efs, k=10):
     np.savez_compressed(os.path.join(GOLDEN, f"{src_name}_filter.npz"), **out)
 
 
+def rabitq_fixture(tmp):
+    """Outputs of the compiled rabitqlib (oracle/_ref/ref_rabitq) for the separable SlimQ pieces."""
+    RQ = os.path.join(ROOT, "oracle", "_ref", "ref_rabitq")
+    out = {}
+    rng = np.random.default_rng(777)
+    for dim, metric in ((128, 0), (96, 0), (768, 1)):
+        padded = (dim + 63) // 64 * 64
+        nd, nq = 48, 6
+        x = (rng.standard_normal((nd, dim)) * 2 + 0.3).astype(np.float32)
+        q = (rng.standard_normal((nq, dim)) * 2 + 0.3).astype(np.float32)
+        cen = (rng.standard_normal((1, dim)) * 0.5).astype(np.float32)
+        f = {k: os.path.join(tmp, f"rq_{k}.bin") for k in ("flip", "x", "q", "c", "rx", "rq", "rc", "codes", "fac", "ga", "ge", "oq", "ob", "oe")}
+        if os.path.exists(f["flip"]):
+            os.remove(f["flip"])
+        x.tofile(f["x"]); q.tofile(f["q"]); cen.tofile(f["c"])
+        subprocess.check_call([RQ, "rotate", str(dim), f["flip"], f["x"], str(nd), f["rx"]])
+        subprocess.check_call([RQ, "rotate", str(dim), f["flip"], f["q"], str(nq), f["rq"]])
+        subprocess.check_call([RQ, "rotate", str(dim), f["flip"], f["c"], "1", f["rc"]])
+        subprocess.check_call([RQ, "data", str(padded), str(metric), f["rx"], str(nd), f["rc"], f["codes"], f["fac"]])
+        ga = rng.uniform(1, 50, nq).astype(np.float32); ge = rng.uniform(1, 7, nq).astype(np.float32)
+        ga.tofile(f["ga"]); ge.tofile(f["ge"])
+        t_const = 41.25 if padded == 128 else 90.5
+        subprocess.check_call([RQ, "query", str(padded), str(metric), repr(t_const), f["rq"], str(nq), f["codes"], f["fac"], str(nd),
+                               f["ga"], f["ge"], f["oq"], f["ob"], f["oe"]])
+        p = f"d{dim}_"
+        out.update({p + "metric": np.array(metric), p + "t_const": np.array(t_const), p + "x": x, p + "q": q, p + "cen": cen,
+                    p + "flip": np.fromfile(f["flip"], np.uint8), p + "rx": np.fromfile(f["rx"], np.float32).reshape(nd, padded),
+                    p + "rq": np.fromfile(f["rq"], np.float32).reshape(nq, padded), p + "rc": np.fromfile(f["rc"], np.float32),
+                    p + "codes": np.fromfile(f["codes"], np.uint64).reshape(nd, padded // 64),
+                    p + "fac": np.fromfile(f["fac"], np.float32).reshape(nd, 3), p + "g_add": ga, p + "g_err": ge,
+                    p + "q3": np.fromfile(f["oq"], np.float32).reshape(nq, 3),
+                    p + "bins": np.fromfile(f["ob"], np.uint64).reshape(nq, padded // 64 * 4),
+                    p + "est": np.fromfile(f["oe"], np.float32).reshape(nq, nd, 3)})
+    np.savez_compressed(os.path.join(GOLDEN, "rabitq_ref.npz"), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -111,6 +147,7 @@ def main():
         deleted_fixture(tmp, "l2_int_d16", "l2", 16, 5, [10, 48])
         filter_fixture(tmp, "l2_cont_d32", "l2", 3, 1, [10, 32, 64])
         filter_fixture(tmp, "l2_int_d16_del", "l2", 4, 0, [10, 48])   # delete marks AND a filter
+        rabitq_fixture(tmp)
     print("golden fixtures written to", GOLDEN)
 
 
