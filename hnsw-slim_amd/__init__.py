@@ -23,7 +23,7 @@ EXPORTS = [
     "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
     "hs_build_hnsw", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
-    "hs_rabitq_estimate",
+    "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst",
 ]
 
 
@@ -76,6 +76,9 @@ def lib():
     L.hs_labels.argtypes = [vp, vp]
     L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
+    L.hs_convert_slimq.argtypes = [ctypes.c_char_p, ci, sz, vp, sz, vp, ctypes.c_uint64, ci, ctypes.c_char_p]
+    L.hs_rabitq_default_tconst.restype = ctypes.c_double
+    L.hs_rabitq_default_tconst.argtypes = [sz, ctypes.c_uint64]
     L.hs_rabitq_rotate.argtypes = [sz, vp, vp, sz, vp]
     L.hs_rabitq_quantize_data.argtypes = [sz, ci, vp, sz, vp, vp, vp]
     L.hs_rabitq_prepare_query.argtypes = [sz, ctypes.c_double, vp, sz, vp, vp]
@@ -105,6 +108,17 @@ def convert_slim(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=
     """HierarchicalNSWSlim::convertFromHNSW + saveIndex, on the CPU (harness)."""
     _check(lib().hs_convert_slim(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
                                  top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
+
+
+def convert_slimq(slim_path, metric, dim, centroids, out_path, cluster_ids=None, flip_seed=1, threads=8):
+    c = np.ascontiguousarray(centroids, np.float32).reshape(-1, dim)
+    cid = None if cluster_ids is None else np.ascontiguousarray(cluster_ids, np.uint32)
+    _check(lib().hs_convert_slimq(slim_path.encode(), metric, dim, c.ctypes.data, c.shape[0], None if cid is None else cid.ctypes.data,
+                                  flip_seed, threads, out_path.encode()))
+
+
+def rabitq_default_tconst(padded_dim, seed=1):
+    return lib().hs_rabitq_default_tconst(padded_dim, seed)
 
 
 def rabitq_rotate(dim, flips, x):

@@ -463,6 +463,31 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
   return HS_OK;
 }
 
+hs_status hs_convert_slimq(const char *slim_path, int metric, size_t dim, const float *centroids, size_t num_cluster,
+                           const uint32_t *cluster_ids, uint64_t flip_seed, int threads, const char *out_path) {
+  if (!slim_path || !out_path || !centroids || num_cluster == 0) return fail(HS_ERR_INVALID, "bad argument");
+  if (dim < 64 || dim >= 4096) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports 64 <= dim < 4096");
+  try {
+    SlimGraph s;
+    s.load(slim_path, (Metric)metric, dim);
+    if (cluster_ids)
+      for (size_t i = 0; i < s.count; i++)
+        if (cluster_ids[i] >= num_cluster) return fail(HS_ERR_INVALID, "cluster id out of range");
+    SlimQGraph q;
+    q.from_slim(s, metric, centroids, num_cluster, cluster_ids, flip_seed, threads);
+    q.save(out_path);
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  return HS_OK;
+}
+double hs_rabitq_default_tconst(size_t padded_dim, uint64_t seed) {
+  if (padded_dim == 0 || padded_dim % 64) return 0.0;
+  return rq_default_tconst(padded_dim, seed);
+}
+
 hs_status hs_rabitq_rotate(size_t dim, const uint8_t *flips, const float *in, size_t n, float *out) {
   if (!flips || !in || !out || dim == 0) return fail(HS_ERR_INVALID, "bad argument");
   Rotator r;

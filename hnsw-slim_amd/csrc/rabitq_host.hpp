@@ -21,6 +21,8 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <limits>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -167,6 +169,57 @@ inline void rq_prepare_query(const float *rq, size_t padded, double t_const, RqQ
       if ((code[i] >> b) & 1) out.bins[(i >> 6) * 4 + b] |= 1ull << (63 - (i & 63));
 }
 
+// faster_config's t_const (rabitqlib/quantization/rabitq.hpp:27-33 -> rabitq_impl.hpp:276-377): the mean optimal
+// rescale factor of 100 random unit vectors.  The reference draws them from std::random_device, i.e. every process
+// gets a slightly different constant (about +-1 % at dim 128); here the generator is seeded.
+inline double rq_best_rescale(const double *o_abs, size_t dim, size_t ex_bits) {
+  static const double tight[9] = {0, 0.15, 0.20, 0.52, 0.59, 0.71, 0.75, 0.77, 0.81};
+  const double mx = *std::max_element(o_abs, o_abs + dim);
+  const double t_end = (double)(((1 << ex_bits) - 1) + 10) / mx;
+  const double t_start = t_end * (double)(float)tight[ex_bits];
+  std::vector<int> cur(dim);
+  double den = (double)dim * 0.25, num = 0;
+  for (size_t i = 0; i < dim; i++) {
+    cur[i] = (int)(t_start * o_abs[i] + 1e-5);
+    den += cur[i] * cur[i] + cur[i];
+    num += (cur[i] + 0.5) * o_abs[i];
+  }
+  using E = std::pair<double, size_t>;
+  std::vector<E> heap;
+  for (size_t i = 0; i < dim; i++) heap.emplace_back((double)(cur[i] + 1) / o_abs[i], i);
+  std::make_heap(heap.begin(), heap.end(), std::greater<E>());
+  double best = 0, t = 0;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), std::greater<E>());
+    const E e = heap.back();
+    heap.pop_back();
+    const int ob = ++cur[e.second];
+    den += 2 * ob;
+    num += o_abs[e.second];
+    const double ip = num / std::sqrt(den);
+    if (ip > best) { best = ip; t = e.first; }
+    if (ob < (1 << ex_bits) - 1) {
+      const double tn = (double)(ob + 1) / o_abs[e.second];
+      if (tn < t_end) { heap.emplace_back(tn, e.second); std::push_heap(heap.begin(), heap.end(), std::greater<E>()); }
+    }
+  }
+  return t;
+}
+inline double rq_default_tconst(size_t padded, uint64_t seed, size_t ex_bits = 3) {
+  std::mt19937 gen((uint32_t)seed);
+  std::normal_distribution<double> nd(0, 1);
+  std::vector<double> v(padded);
+  double sum = 0;
+  for (int j = 0; j < 100; j++) {
+    double n2 = 0;
+    for (auto &x : v) { x = nd(gen); n2 += x * x; }
+    const double inv = 1.0 / std::sqrt(n2);
+    for (auto &x : v) x = std::fabs(x * inv);
+    sum += rq_best_rescale(v.data(), padded, ex_bits);
+  }
+  return sum / 100;
+}
+
 // ------------------------------------------------------------------------------------------------
 // HierarchicalNSWSlimQ file image.
 struct SlimQGraph {
@@ -262,16 +315,14 @@ struct SlimQGraph {
     }
   }
 
-  // CPU harness: graph = HNSW built on the raw vectors with exact distances, pruned by convertFromHNSW
-  // (hnswalg_slim.h:867-1108; the reference builds its SlimQ graph with rabitqlib's own HNSW and estimated
-  // distances, hnsw_slimq_strategy.h:101-133 -- the search path only needs A valid SlimQ file), then every
-  // vector is rotated and 1-bit quantised against the rotated centroid of its cluster.
-  void build(const float *base, size_t n, size_t d, int metric_, size_t M_, size_t efC_, const SlimParams &sp,
-             const float *cent_raw, size_t ncl, const uint32_t *cluster_ids, uint64_t flip_seed, int threads) {
-    VanillaGraph g;
-    g.build(base, n, d, (Metric)metric_, M_, efC_, "4", 100, threads);
-    SlimGraph s;
-    s.convert(g, sp, threads);
+  // CPU harness: take the graph of a HierarchicalNSWSlim file as it is and quantise its vectors.  (The reference
+  // derives its SlimQ graph from rabitqlib's own HNSW, built with ESTIMATED distances -- hnsw_slimq_strategy.h:101-133,
+  // hnswalg_slimq.h:1471-1790; the search path only needs A valid SlimQ file, and a graph built with exact distances
+  // is the better graph.)  Every vector is rotated and 1-bit quantised against the rotated centroid of its cluster
+  // (nearest raw centroid when cluster_ids is null).
+  void from_slim(const SlimGraph &s, int metric_, const float *cent_raw, size_t ncl, const uint32_t *cluster_ids,
+                 uint64_t flip_seed, int threads) {
+    const size_t n = s.count, d = s.dim;
     count = n; dim = d; padded = rq_padded(d); metric = metric_; num_cluster = ncl;
     maxM = s.maxM; maxM0 = s.maxM0; M = s.M; efC = s.efC; maxlevel = s.maxlevel; threshold_level = s.threshold_level;
     enterpoint = s.enterpoint;
@@ -295,12 +346,12 @@ struct SlimQGraph {
             float best = std::numeric_limits<float>::max();
             cid = 0;
             for (size_t c = 0; c < ncl; c++) {
-              float dd = rq_l2sqr(base + i * d, cent_raw + c * d, d);
+              float dd = rq_l2sqr(s.vec(i), cent_raw + c * d, d);
               if (dd < best) { best = dd; cid = (uint32_t)c; }
             }
           }
           cluster[i] = cid;
-          rot.rotate(base + i * d, rx.data());
+          rot.rotate(s.vec(i), rx.data());
           rq_quantize_data(rx.data(), &centroids[cid * padded], padded, metric, &code[i * padded / 64], &factors[i * 3]);
         }
       });

@@ -131,6 +131,15 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
                           size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int threads,
                           const char *out_path);
 
+/* HierarchicalNSWSlimQ::convertFromHNSW's OUTPUT format + saveIndex (hnswalg_slimq.h:1471-1790, 1161-1216): keeps
+ * the graph of an existing HierarchicalNSWSlim file and replaces the fp32 rows by RaBitQ records (cluster id,
+ * 1-bit code, {f_add, f_rescale, f_error}); the ex-bits area is zero (no function on the search path reads it).
+ * centroids: num_cluster x dim raw vectors; cluster_ids: n ids or NULL (= nearest centroid). */
+hs_status hs_convert_slimq(const char *slim_path, int metric, size_t dim, const float *centroids, size_t num_cluster,
+                           const uint32_t *cluster_ids, uint64_t flip_seed, int threads, const char *out_path);
+/* quant::faster_config(padded, 4).t_const (rabitqlib/quantization/rabitq.hpp:27-33) with a seeded generator. */
+double hs_rabitq_default_tconst(size_t padded_dim, uint64_t seed);
+
 /* ---- RaBitQ pieces of the HNSW-SlimQ path (CPU; used by the SlimQ harness and query preparation, exposed
  *      so that tests can pin them against the compiled rabitqlib) ------------------------------------- */
 /* FhtKacRotator::rotate: rabitqlib/utils/rotator.hpp:370-423.  flips = 4*padded/8 bytes, out = n x padded. */

@@ -1,6 +1,7 @@
 // oracle/oracle_capi.cpp -- TEST INFRASTRUCTURE ONLY: C entry points over hs_oracle.hpp for ctypes
 // (tests/, smoke(), bench.py cpu_baseline).  Never linked into the product library.
 #include "hs_oracle.hpp"
+#include "hs_oracle_slimq.hpp"
 #include <omp.h>
 
 using namespace hso;
@@ -106,6 +107,76 @@ int hso_brute_force(int metric, const float *base, size_t n, size_t d, const flo
                     uint32_t *out, int threads) {
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
   for (long i = 0; i < (long)nq; i++) brute_force((Metric)metric, base, n, d, q + i * d, k, out + i * k);
+  return 0;
+}
+
+// ---- HNSW-SlimQ ---------------------------------------------------------------------------------------------
+void *hso_slimq_load(const char *path) {
+  try { auto *ix = new SlimQIndex(); ix->load(path); return ix; }
+  catch (std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void hso_slimq_free(void *p) { delete (SlimQIndex *)p; }
+void hso_slimq_set(void *p, size_t ef, double t_const, const float *raw) {
+  auto *ix = (SlimQIndex *)p; ix->ef = ef; ix->t_const = t_const; ix->raw = raw;
+}
+void hso_slimq_info(void *p, uint64_t *out) {
+  auto *ix = (SlimQIndex *)p;
+  out[0] = ix->count; out[1] = ix->dim; out[2] = ix->padded; out[3] = ix->ncl; out[4] = (uint64_t)ix->maxlevel;
+  out[5] = ix->enterpoint; out[6] = (uint64_t)ix->metric; out[7] = (uint64_t)ix->threshold_level;
+}
+// Piece-wise entry points with explicit operands (pinned against tests/golden/rabitq_ref.npz).
+void hso_rq_rotate(size_t dim, const uint8_t *flips, const float *x, size_t n, float *out) {
+  SlimQIndex ix;
+  ix.dim = dim; ix.padded = (dim + 63) / 64 * 64;
+  ix.flips.assign(flips, flips + 4 * ix.padded / 8);
+  for (size_t i = 0; i < n; i++) ix.rotate(x + i * dim, out + i * ix.padded);
+}
+// q3 n x {delta, vl, k1xsumq}; planes n x padded/64*4; q2c n x (ncl or 2 ncl for IP)
+void hso_rq_prepare(size_t padded, int metric, double t_const, const float *rq, size_t n, const float *cent, size_t ncl,
+                    float *q3, uint64_t *planes, float *q2c) {
+  SlimQIndex ix;
+  ix.padded = padded; ix.metric = metric; ix.t_const = t_const; ix.ncl = ncl;
+  ix.cent.assign(cent, cent + ncl * padded);
+  SlimQIndex::Query Q;
+  for (size_t i = 0; i < n; i++) {
+    ix.prepare(rq + i * padded, Q);
+    q3[i * 3] = Q.delta; q3[i * 3 + 1] = Q.vl; q3[i * 3 + 2] = Q.k1xsumq;
+    std::copy(Q.planes.begin(), Q.planes.end(), planes + i * Q.planes.size());
+    std::copy(Q.q2c.begin(), Q.q2c.end(), q2c + i * Q.q2c.size());
+  }
+}
+// out nq x nd estimated distances with the query-side g_add given per query
+void hso_rq_est(size_t padded, int metric, const uint64_t *codes, const float *fac, size_t nd, const float *q3,
+                const uint64_t *planes, const float *g_add, size_t nq, float *out) {
+  SlimQIndex ix;
+  ix.padded = padded; ix.metric = metric; ix.ncl = 1;
+  ix.code.assign(codes, codes + nd * padded / 64);
+  ix.fac.assign(fac, fac + nd * 3);
+  ix.cid.assign(nd, 0);
+  SlimQIndex::Query Q;
+  for (size_t i = 0; i < nq; i++) {
+    Q.delta = q3[i * 3]; Q.vl = q3[i * 3 + 1]; Q.k1xsumq = q3[i * 3 + 2];
+    Q.planes.assign(planes + i * padded / 64 * 4, planes + (i + 1) * padded / 64 * 4);
+    for (size_t j = 0; j < nd; j++) out[i * nd + j] = ix.est_g(Q, (uint32_t)j, g_add[i]);
+  }
+}
+// out_ids/out_d: nq x k in the reference's heap-array order (labels), out_cnt = entries found, counters nq x 4.
+int hso_slimq_search(void *p, const float *q, size_t nq, size_t k, uint64_t *out_l, float *out_d, uint32_t *out_cnt,
+                     uint64_t *counters, int threads) {
+  auto *ix = (SlimQIndex *)p;
+  if (!ix->raw || ix->t_const <= 0) { g_err = "dataset / t_const not set"; return 1; }
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+  for (long i = 0; i < (long)nq; i++) {
+    std::vector<std::pair<float, uint32_t>> heap;
+    SlimQCounters c;
+    size_t f = slimq_search(*ix, q + i * ix->dim, k, heap, &c);
+    out_cnt[i] = (uint32_t)f;
+    for (size_t j = 0; j < k; j++) {
+      out_l[i * k + j] = j < f ? ix->label[heap[j].second] : ~0ull;
+      out_d[i * k + j] = j < f ? heap[j].first : std::numeric_limits<float>::infinity();
+    }
+    if (counters) { counters[i * 4] = c.n_hops; counters[i * 4 + 1] = c.n_est; counters[i * 4 + 2] = c.n_insert; counters[i * 4 + 3] = c.n_revisit; }
+  }
   return 0;
 }
 }

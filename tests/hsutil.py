@@ -109,7 +109,50 @@ class Oracle:
         L.hso_search_pq.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp, ctypes.c_int]
         L.hso_dist.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
         L.hso_brute_force.argtypes = [ctypes.c_int, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_int]
+        sz, dbl, ci = ctypes.c_size_t, ctypes.c_double, ctypes.c_int
+        L.hso_slimq_load.restype = vp
+        L.hso_slimq_load.argtypes = [ctypes.c_char_p]
+        L.hso_slimq_free.argtypes = [vp]
+        L.hso_slimq_set.argtypes = [vp, sz, dbl, vp]
+        L.hso_slimq_info.argtypes = [vp, vp]
+        L.hso_slimq_search.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, ci]
+        L.hso_rq_rotate.argtypes = [sz, vp, vp, sz, vp]
+        L.hso_rq_prepare.argtypes = [sz, ci, dbl, vp, sz, vp, sz, vp, vp, vp]
+        L.hso_rq_est.argtypes = [sz, ci, vp, vp, sz, vp, vp, vp, sz, vp]
         self.L = L
+
+    def rq_rotate(self, dim, flips, x):
+        x = np.ascontiguousarray(x, np.float32)
+        flips = np.ascontiguousarray(flips, np.uint8)
+        out = np.empty((x.shape[0], (dim + 63) // 64 * 64), np.float32)
+        self.L.hso_rq_rotate(dim, flips.ctypes.data, x.ctypes.data, x.shape[0], out.ctypes.data)
+        return out
+
+    def rq_prepare(self, rq, metric, t_const, cent):
+        rq = np.ascontiguousarray(rq, np.float32)
+        cent = np.ascontiguousarray(cent, np.float32).reshape(-1, rq.shape[1])
+        n, padded = rq.shape
+        ncl = cent.shape[0]
+        q3 = np.empty((n, 3), np.float32)
+        planes = np.empty((n, padded // 64 * 4), np.uint64)
+        q2c = np.empty((n, ncl * (2 if metric == 1 else 1)), np.float32)
+        self.L.hso_rq_prepare(padded, metric, float(t_const), rq.ctypes.data, n, cent.ctypes.data, ncl, q3.ctypes.data,
+                              planes.ctypes.data, q2c.ctypes.data)
+        return q3, planes, q2c
+
+    def rq_est(self, metric, codes, fac, q3, planes, g_add):
+        a = [np.ascontiguousarray(x) for x in (codes, fac, q3, planes, np.asarray(g_add, np.float32))]
+        nd, nq = codes.shape[0], q3.shape[0]
+        out = np.empty((nq, nd), np.float32)
+        self.L.hso_rq_est(codes.shape[1] * 64, metric, a[0].ctypes.data, a[1].ctypes.data, nd, a[2].ctypes.data, a[3].ctypes.data,
+                          a[4].ctypes.data, nq, out.ctypes.data)
+        return out
+
+    def load_slimq(self, path):
+        h = self.L.hso_slimq_load(path.encode())
+        if not h:
+            raise RuntimeError(self.err())
+        return OracleSlimQ(self, h)
 
     def err(self):
         return self.L.hso_last_error().decode()
@@ -135,6 +178,42 @@ class Oracle:
         if not h:
             raise RuntimeError(self.err())
         return OracleIndex(self, h, kind, dim)
+
+
+class OracleSlimQ:
+    """HierarchicalNSWSlimQ restatement (oracle/hs_oracle_slimq.hpp)."""
+
+    def __init__(self, o, h):
+        self.o, self.h = o, h
+        info = np.zeros(8, np.uint64)
+        o.L.hso_slimq_info(h, info.ctypes.data)
+        self.count, self.dim, self.padded, self.ncl, self.maxlevel, self.enterpoint, self.metric, self.threshold_level = (int(x) for x in info)
+        self._raw = None
+
+    def __del__(self):
+        try:
+            self.o.L.hso_slimq_free(self.h)
+        except Exception:
+            pass
+
+    def set(self, ef, t_const, raw):
+        self._raw = np.ascontiguousarray(raw, np.float32)
+        assert self._raw.shape == (self.count, self.dim)
+        self.o.L.hso_slimq_set(self.h, ef, float(t_const), self._raw.ctypes.data)
+
+    def search(self, q, k, threads=1):
+        """searchKnn(q, k, result): labels/dists in the reference's heap-array order, count found, counters
+        {hops, estimates, pool inserts, revisits}."""
+        q = np.ascontiguousarray(q, np.float32)
+        nq = q.shape[0]
+        lab = np.empty((nq, k), np.uint64)
+        d = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        ctr = np.zeros((nq, 4), np.uint64)
+        rc = self.o.L.hso_slimq_search(self.h, q.ctypes.data, nq, k, lab.ctypes.data, d.ctypes.data, cnt.ctypes.data, ctr.ctypes.data, threads)
+        if rc:
+            raise RuntimeError(self.o.err())
+        return dict(labels=lab, dists=d, counts=cnt, counters=ctr)
 
 
 class OracleIndex:

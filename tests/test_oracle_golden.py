@@ -85,3 +85,22 @@ def test_vanilla_filtered_search_matches_reference(oracle, name, dim):
         assert np.array_equal(r["labels"], g[f"ef{ef}_labels"])
         assert r["dists"].tobytes() == g[f"ef{ef}_dists"].tobytes()
         assert np.array_equal(r["counters"][:, 0], g[f"ef{ef}_calls"])
+
+
+# ---- RaBitQ pieces of the SlimQ oracle against the compiled rabitqlib ------------------------------------------
+RQ = np.load(os.path.join(GOLDEN, "rabitq_ref.npz"))
+
+
+@pytest.mark.parametrize("dim", (128, 96, 768))
+def test_slimq_oracle_pieces_match_rabitqlib(oracle, dim):
+    p = f"d{dim}_"
+    metric, t_const = int(RQ[p + "metric"]), float(RQ[p + "t_const"])
+    for src, dst in (("x", "rx"), ("q", "rq")):
+        got = oracle.rq_rotate(dim, RQ[p + "flip"], RQ[p + src])
+        assert np.array_equal(got.view(np.uint32), RQ[p + dst].view(np.uint32))
+    q3, planes, q2c = oracle.rq_prepare(RQ[p + "rq"], metric, t_const, RQ[p + "rc"])
+    scale = np.abs(RQ[p + "q3"]).max(axis=0, keepdims=True)
+    assert np.all(np.abs(q3 - RQ[p + "q3"]) <= 1e-4 * scale)
+    assert np.array_equal(planes, RQ[p + "bins"])
+    est = oracle.rq_est(metric, RQ[p + "codes"], RQ[p + "fac"], RQ[p + "q3"], RQ[p + "bins"], RQ[p + "g_add"])
+    assert np.array_equal(est.view(np.uint32), RQ[p + "est"][:, :, 1].view(np.uint32))
