@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HS_LIB", os.path.join(_HERE, "libhnsw_slim_amd.so"))  # HS_LIB: diagnostic builds only
 
-HS_KIND_HNSW, HS_KIND_SLIM = 0, 1
+HS_KIND_HNSW, HS_KIND_SLIM, HS_KIND_SLIMQ = 0, 1, 2
 HS_METRIC_L2, HS_METRIC_IP = 0, 1
 HS_MODE_SLIM_IDS, HS_MODE_PQ = 0, 1
 HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORTED, HS_ERR_DEVICE, HS_ERR_CAPACITY = range(8)
@@ -23,7 +23,8 @@ EXPORTS = [
     "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
     "hs_build_hnsw", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
-    "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst",
+    "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
+    "hs_slimq_search_batch", "hs_slimq_search_batch_dev",
 ]
 
 
@@ -79,6 +80,12 @@ def lib():
     L.hs_convert_slimq.argtypes = [ctypes.c_char_p, ci, sz, vp, sz, vp, ctypes.c_uint64, ci, ctypes.c_char_p]
     L.hs_rabitq_default_tconst.restype = ctypes.c_double
     L.hs_rabitq_default_tconst.argtypes = [sz, ctypes.c_uint64]
+    L.hs_slimq_set_dataset.argtypes = [vp, vp, sz, sz]
+    L.hs_slimq_set_tconst.argtypes = [vp, ctypes.c_double]
+    L.hs_slimq_get_tconst.restype = ctypes.c_double
+    L.hs_slimq_get_tconst.argtypes = [vp]
+    L.hs_slimq_search_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
+    L.hs_slimq_search_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.hs_rabitq_rotate.argtypes = [sz, vp, vp, sz, vp]
     L.hs_rabitq_quantize_data.argtypes = [sz, ci, vp, sz, vp, vp, vp]
     L.hs_rabitq_prepare_query.argtypes = [sz, ctypes.c_double, vp, sz, vp, vp]
@@ -219,6 +226,30 @@ class Index:
         stats = np.empty((nq, 4), np.uint32) if want_stats else None
         _check(lib().hs_search_batch(self._h, q.ctypes.data, nq, k, HS_MODE_PQ, None, labels.ctypes.data, dists.ctypes.data,
                                      cnt.ctypes.data, stats.ctypes.data if want_stats else None))
+        return dict(labels=labels, dists=dists, cnt=cnt, stats=stats)
+
+    # ---- HNSW-SlimQ (kind == HS_KIND_SLIMQ) ----
+    def slimq_set_dataset(self, base):
+        """HierarchicalNSWSlimQ::setDataset: raw rows by internal id, used for the exact re-rank."""
+        b = np.ascontiguousarray(base, np.float32)
+        _check(lib().hs_slimq_set_dataset(self._h, b.ctypes.data, b.shape[0], b.shape[1]))
+
+    def slimq_set_tconst(self, t_const):
+        _check(lib().hs_slimq_set_tconst(self._h, float(t_const)))
+
+    def slimq_tconst(self):
+        return lib().hs_slimq_get_tconst(self._h)
+
+    def slimq_search(self, queries, k, want_stats=False):
+        """searchKnn(q, k, result) of HierarchicalNSWSlimQ: labels/dists in the reference's heap-array order."""
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        labels = np.empty((nq, k), np.uint64)
+        dists = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        stats = np.empty((nq, 4), np.uint32) if want_stats else None
+        _check(lib().hs_slimq_search_batch(self._h, q.ctypes.data, nq, k, labels.ctypes.data, dists.ctypes.data, cnt.ctypes.data,
+                                           stats.ctypes.data if want_stats else None))
         return dict(labels=labels, dists=dists, cnt=cnt, stats=stats)
 
     def labels(self):

@@ -18,6 +18,7 @@
 #include "host_graph.hpp"
 #include "rabitq_est.hpp"
 #include "rabitq_host.hpp"
+#include "slimq_engine.hpp"
 
 using namespace hs;
 
@@ -31,7 +32,7 @@ static hs_status from_exception(const std::exception &e) {
   if (m == "Cannot open file") return fail(HS_ERR_IO, m);
   if (m.find("corrupted") != std::string::npos) return fail(HS_ERR_CORRUPT, m);
   if (m.find("Not enough memory") != std::string::npos) return fail(HS_ERR_NOMEM, m);
-  if (m.find("supports dim") != std::string::npos) return fail(HS_ERR_UNSUPPORTED, m);
+  if (m.find("supports dim") != std::string::npos || m.find("SlimQ supports") != std::string::npos) return fail(HS_ERR_UNSUPPORTED, m);
   return fail(HS_ERR_INVALID, m);
 }
 #define HIP_TRY(expr)                                                                          \
@@ -98,6 +99,13 @@ struct hs_index {
   std::vector<uint64_t> host_labels;   // external labels by internal id
   std::vector<uint8_t> host_deleted;   // delete marks by internal id
   DevBuf<uint8_t> wexcl;               // deleted | !allowed of the current filtered call
+  // HNSW-SlimQ (kind == HS_KIND_SLIMQ): RaBitQ records, rotated centroids, rotator flips; `vec` then holds the
+  // dataset rows of hs_slimq_set_dataset()
+  DevBuf<uint32_t> q_rec;
+  DevBuf<float> q_cent;
+  DevBuf<uint8_t> q_flips;
+  DevSlimQ sq{};
+  bool has_dataset = false;
 };
 
 static uint32_t next_pow2(uint32_t v) {
@@ -194,6 +202,53 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   return HS_OK;
 }
 
+// HierarchicalNSWSlimQ::loadIndex (hnswalg_slimq.h:1218-1313): graph -> CSR/tiles, element records -> 16-byte header
+// {f_add, f_rescale, cluster id, f_error} + sign code, rotated centroids and rotator flips as they are.
+static hs_status load_slimq(const char *path, int metric, size_t dim, int device, hs_index **out) {
+  SlimQGraph q;
+  PackedIndex p;
+  try {
+    q.load(path, metric, dim);
+    if (q.rot.trunc < 64) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports dim >= 64");
+    p.kind = HS_KIND_SLIMQ; p.metric = (Metric)metric; p.n = q.count; p.dim = dim;
+    p.maxlevel = q.maxlevel; p.threshold_level = q.threshold_level; p.enterpoint = q.enterpoint;
+    p.labels = q.label;
+    p.deleted.assign(q.count, 0);
+    p.pack_chal([&](size_t i) { return (int)q.level[i]; }, [&](size_t i) { return (size_t)q.total(i); },
+                [&](size_t i) -> const std::vector<char> & { return q.blobs[i]; });
+    if (q.count && q.enterpoint >= q.count) return fail(HS_ERR_CORRUPT, "Index seems to be corrupted or unsupported");
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory: loadIndex failed to allocate");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  hs_index *ix = new hs_index();
+  ix->device = device;
+  hs_status s = upload(ix, p);
+  if (s != HS_OK) { delete ix; return s; }
+  const uint32_t nblk = (uint32_t)(q.padded / 64), rw = (4 + 2 * nblk + 3) & ~3u;  // 16-byte multiple
+  std::vector<uint32_t> rec((size_t)q.count * rw);
+  for (size_t i = 0; i < q.count; i++) {
+    uint32_t *r = &rec[i * rw];
+    memcpy(r, &q.factors[i * 3], 4); memcpy(r + 1, &q.factors[i * 3 + 1], 4);
+    r[2] = q.cluster[i];
+    memcpy(r + 3, &q.factors[i * 3 + 2], 4);
+    memcpy(r + 4, &q.code[i * nblk], 8 * nblk);
+  }
+  hipError_t e = ix->q_rec.upload(rec);
+  if (e == hipSuccess) e = ix->q_cent.upload(q.centroids);
+  if (e == hipSuccess) e = ix->q_flips.upload(q.rot.flip);
+  if (e != hipSuccess) { delete ix; return fail(HS_ERR_DEVICE, std::string("SlimQ upload: ") + hipGetErrorString(e)); }
+  DevSlimQ &d = ix->sq;
+  d.rec = ix->q_rec.p; d.raw = nullptr; d.cent = ix->q_cent.p; d.flips = ix->q_flips.p;
+  d.rec_words = rw; d.padded = (uint32_t)q.padded; d.trunc = (uint32_t)q.rot.trunc; d.ncl = (uint32_t)q.num_cluster;
+  d.fht_scale = q.rot.fac;
+  d.t_const = rq_default_tconst(q.padded, 1);
+  ix->info.device_bytes += rec.size() * 4 + q.centroids.size() * 4 + q.rot.flip.size();
+  *out = ix;
+  return HS_OK;
+}
+
 hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements, int device,
                         hs_index **out) {
   if (!path || !out) return fail(HS_ERR_INVALID, "null argument");
@@ -211,6 +266,8 @@ hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size
       SlimGraph g;
       g.load(path, (Metric)metric, dim);
       p.from_slim(g);
+    } else if (kind == HS_KIND_SLIMQ) {
+      return load_slimq(path, metric, dim, device, out);
     } else {
       return fail(HS_ERR_INVALID, "bad index kind");
     }
@@ -261,6 +318,7 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   if (!ix) return fail(HS_ERR_INVALID, "null index");
   if (k == 0) return fail(HS_ERR_INVALID, "k must be > 0");
   if (mode != HS_MODE_SLIM_IDS && mode != HS_MODE_PQ) return fail(HS_ERR_INVALID, "bad mode");
+  if (ix->info.kind == HS_KIND_SLIMQ) return fail(HS_ERR_INVALID, "SlimQ index: use hs_slimq_search_batch");
   if (mode == HS_MODE_SLIM_IDS && ix->info.kind != HS_KIND_SLIM)
     return fail(HS_ERR_INVALID, "HS_MODE_SLIM_IDS needs a Slim index (searchKnn(q,k,tableint*) exists on HierarchicalNSWSlim only)");
   if (nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "nq too large");
@@ -319,6 +377,10 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   const size_t nq = std::max<size_t>(w->last_nq, 1);
   if ((size_t)c[3] * 10 > nq && ix->grow_hash < 8 && !ix->user_hash_slots) ix->grow_hash++;
   if ((size_t)(c[1] + c[5]) * 100 > nq && ix->grow_cand < 4 && !ix->user_cand_cap) ix->grow_cand++;
+  if (ix->info.kind == HS_KIND_SLIMQ) {
+    if (c[8] > 0) return fail(HS_ERR_CAPACITY, std::to_string(c[8]) + " queries expanded more nodes than the 64 KiB on-chip set holds");
+    return HS_OK;
+  }
   if (c[8] + c[9] > 0)
     return fail(HS_ERR_CAPACITY, std::to_string(c[8] + c[9]) + " queries exhausted even a whole CU's on-chip scratch");
   return HS_OK;
@@ -387,6 +449,89 @@ hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t 
   if (mode == HS_MODE_PQ && (!out_labels64 || !out_dists || !out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
   return search_host(ix, queries, nq, k, mode, out_labels32, out_labels64, out_dists, out_counts, stats, nullptr,
                      nullptr, nullptr);
+}
+
+// ---- HNSW-SlimQ ------------------------------------------------------------------------------------------------
+hs_status hs_slimq_set_dataset(hs_index *ix, const float *base, size_t n, size_t dim) {
+  if (!ix || !base) return fail(HS_ERR_INVALID, "null argument");
+  if (ix->info.kind != HS_KIND_SLIMQ) return fail(HS_ERR_INVALID, "not a SlimQ index");
+  if (n != ix->info.n || dim != ix->info.dim) return fail(HS_ERR_INVALID, "dataset shape does not match the index");
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(ix->vec.alloc(std::max<size_t>(n * dim, 1)));
+  HIP_TRY(hipMemcpy(ix->vec.p, base, n * dim * sizeof(float), hipMemcpyHostToDevice));
+  ix->dev.vec = ix->vec.p;
+  ix->sq.raw = ix->vec.p;
+  ix->has_dataset = true;
+  ix->info.device_bytes += n * dim * 4;
+  return HS_OK;
+}
+hs_status hs_slimq_set_tconst(hs_index *ix, double t_const) {
+  if (!ix || !(t_const > 0)) return fail(HS_ERR_INVALID, "bad argument");
+  if (ix->info.kind != HS_KIND_SLIMQ) return fail(HS_ERR_INVALID, "not a SlimQ index");
+  ix->sq.t_const = t_const;
+  return HS_OK;
+}
+double hs_slimq_get_tconst(const hs_index *ix) { return ix && ix->info.kind == HS_KIND_SLIMQ ? ix->sq.t_const : 0.0; }
+
+static constexpr uint32_t kSlimQMaxHash = 16384;  // 64 KiB of LDS: the second pass's expanded-node set
+
+hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, size_t k, uint64_t *d_out_labels,
+                                    float *d_out_dists, uint32_t *d_out_counts, uint32_t *d_stats, void *stream_) {
+  if (!ix || !d_queries || !d_out_labels || !d_out_dists || !d_out_counts) return fail(HS_ERR_INVALID, "null argument");
+  if (ix->info.kind != HS_KIND_SLIMQ) return fail(HS_ERR_INVALID, "not a SlimQ index");
+  if (!ix->has_dataset) return fail(HS_ERR_INVALID, "hs_slimq_set_dataset() first (setDataset, hnswalg_slimq.h:303)");
+  if (k == 0 || k > 1024) return fail(HS_ERR_INVALID, "k must be in 1..1024");
+  if (!slimq_supported((uint32_t)ix->ef)) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports 1 <= ef <= 512");
+  if (nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "nq too large");
+  if (nq == 0) return HS_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_TRY(hipSetDevice(ix->device));
+  hs_index::StreamWs *w = ix->stream_ws(stream);
+  HIP_TRY(w->status.ensure(nq));
+  HIP_TRY(w->counters.ensure(12));
+  HIP_TRY(hipMemsetAsync(w->status.p, 0, nq * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
+  w->last_nq = nq;
+  SlimQArgs a{};
+  a.queries = d_queries; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.pool_cap = (uint32_t)ix->ef;
+  // expansions per query stay below ~ef on real graphs; 75 % fill of 4 ef slots leaves 3x headroom, and a query
+  // that still outgrows it is redone with the 64 KiB set
+  a.hash_slots = ix->user_hash_slots ? next_pow2(ix->user_hash_slots) : next_pow2(std::max<uint32_t>(256, 4 * (uint32_t)ix->ef));
+  a.hash_slots = std::min(a.hash_slots, kSlimQMaxHash);
+  a.out_labels = d_out_labels; a.out_dists = d_out_dists; a.out_counts = d_out_counts; a.stats = d_stats;
+  a.status = w->status.p;
+  a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p;
+  HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
+  if (a.hash_slots < kSlimQMaxHash) {
+    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.hash_slots = kSlimQMaxHash;
+    a.counters = w->counters.p + 8;
+    HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
+  }
+  return HS_OK;
+}
+
+hs_status hs_slimq_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, uint64_t *out_labels,
+                                float *out_dists, uint32_t *out_counts, uint32_t *stats) {
+  if (!ix || !queries || !out_labels) return fail(HS_ERR_INVALID, "null argument");
+  if (nq == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t dim = ix->info.dim;
+  HIP_TRY(ix->wq.ensure(nq * dim));
+  HIP_TRY(ix->wl64.ensure(nq * k));
+  HIP_TRY(ix->wdist.ensure(nq * k));
+  HIP_TRY(ix->wcnt.ensure(nq));
+  HIP_TRY(ix->wstats.ensure(nq * 4));
+  hipStream_t st = nullptr;
+  HIP_TRY(hipMemcpyAsync(ix->wq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+  hs_status s = hs_slimq_search_batch_dev(ix, ix->wq.p, nq, k, ix->wl64.p, ix->wdist.p, ix->wcnt.p, ix->wstats.p, st);
+  if (s != HS_OK) return s;
+  s = hs_search_check(ix, st);
+  if (s != HS_OK) return s;
+  HIP_TRY(hipMemcpy(out_labels, ix->wl64.p, nq * k * 8, hipMemcpyDeviceToHost));
+  if (out_dists) HIP_TRY(hipMemcpy(out_dists, ix->wdist.p, nq * k * 4, hipMemcpyDeviceToHost));
+  if (out_counts) HIP_TRY(hipMemcpy(out_counts, ix->wcnt.p, nq * 4, hipMemcpyDeviceToHost));
+  if (stats) HIP_TRY(hipMemcpy(stats, ix->wstats.p, nq * 16, hipMemcpyDeviceToHost));
+  return HS_OK;
 }
 
 hs_status hs_labels(const hs_index *ix, uint64_t *out_labels) {

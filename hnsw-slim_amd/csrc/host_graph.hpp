@@ -618,26 +618,24 @@ struct PackedIndex {
     if (cols.size() >= NONE) throw std::runtime_error("adjacency too large for 32-bit CSR offsets");
   }
 
-  void from_slim(const SlimGraph &g) {
-    kind = 1; metric = g.metric; n = g.count; dim = g.dim;
-    maxlevel = g.maxlevel; threshold_level = g.threshold_level; enterpoint = g.enterpoint;
-    has_deleted = g.has_deleted;
-    vec.resize(n * dim); labels.resize(n); deleted.resize(n);
+  // CHAL blobs ([u16 cumulative offsets x level][u32 ids x total], hnswalg_slim.h:1981-2000) -> CSR.
+  // level_of(i), total_of(i), blob_of(i) -> const std::vector<char>&
+  template <class LF, class TF, class BF>
+  void pack_chal(LF level_of, TF total_of, BF blob_of) {
     row_ptr0.assign(n + 1, 0); up_base.assign(n, NONE); up_ptr.clear(); cols.clear();
     auto slice = [&](size_t i, int lvl, const uint32_t *&ids, size_t &cnt) {
-      int L = g.level(i);
-      const uint16_t *off = (const uint16_t *)g.blobs[i].data();
+      const int L = level_of(i);
+      const std::vector<char> &blob = blob_of(i);
+      const uint16_t *off = (const uint16_t *)blob.data();
       size_t s = lvl == 0 ? 0 : off[lvl - 1];
-      size_t e = lvl == L ? g.total(i) : off[lvl];
-      if (e < s || e > g.total(i)) throw std::runtime_error("Index seems to be corrupted or unsupported");
-      ids = (const uint32_t *)(g.blobs[i].data() + 2 * (size_t)L) + s;
+      size_t e = lvl == L ? total_of(i) : off[lvl];
+      if (e < s || e > total_of(i) || blob.size() < 2 * (size_t)L + 4 * (size_t)total_of(i))
+        throw std::runtime_error("Index seems to be corrupted or unsupported");
+      ids = (const uint32_t *)(blob.data() + 2 * (size_t)L) + s;
       cnt = e - s;
     };
     for (size_t i = 0; i < n; i++) {
-      memcpy(&vec[i * dim], g.vec(i), 4 * dim);
-      labels[i] = g.label(i);
-      deleted[i] = g.deleted(i);
-      if (!g.blobs[i].empty()) {
+      if (!blob_of(i).empty()) {
         const uint32_t *ids; size_t c;
         slice(i, 0, ids, c);
         max_deg0 = std::max(max_deg0, c);
@@ -646,8 +644,8 @@ struct PackedIndex {
       row_ptr0[i + 1] = cols.size();
     }
     for (size_t i = 0; i < n; i++) {
-      int L = g.level(i);
-      if (L <= 0 || g.blobs[i].empty()) continue;
+      const int L = level_of(i);
+      if (L <= 0 || blob_of(i).empty()) continue;
       up_base[i] = up_ptr.size();
       for (int l = 1; l <= L; l++) {
         up_ptr.push_back(cols.size());
@@ -659,6 +657,20 @@ struct PackedIndex {
     }
     for (uint32_t c : cols) if (c >= n) throw std::runtime_error("Index seems to be corrupted or unsupported");
     if (cols.size() >= NONE) throw std::runtime_error("adjacency too large for 32-bit CSR offsets");
+  }
+
+  void from_slim(const SlimGraph &g) {
+    kind = 1; metric = g.metric; n = g.count; dim = g.dim;
+    maxlevel = g.maxlevel; threshold_level = g.threshold_level; enterpoint = g.enterpoint;
+    has_deleted = g.has_deleted;
+    vec.resize(n * dim); labels.resize(n); deleted.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      memcpy(&vec[i * dim], g.vec(i), 4 * dim);
+      labels[i] = g.label(i);
+      deleted[i] = g.deleted(i);
+    }
+    pack_chal([&](size_t i) { return (int)g.level(i); }, [&](size_t i) { return (size_t)g.total(i); },
+              [&](size_t i) -> const std::vector<char> & { return g.blobs[i]; });
   }
 };
 

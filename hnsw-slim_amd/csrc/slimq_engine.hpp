@@ -1,0 +1,36 @@
+// slimq_engine.hpp -- device view + launch interface of the HNSW-SlimQ (RaBitQ) search path.
+#pragma once
+#include "engine.hpp"
+
+namespace hs {
+
+// RaBitQ side of a SlimQ index resident in HBM; the graph itself (tile0 / CSR / labels) lives in DevIndex.
+struct DevSlimQ {
+  const uint32_t *rec;    // n x rec_words: {f_add, f_rescale, cluster id, f_error}, then padded/64 u64 sign-code words
+  const float *raw;       // n x dim: the dataset rows of setDataset(), by INTERNAL id (hnswalg_slimq.h:748)
+  const float *cent;      // ncl x padded: rotated centroids
+  const uint8_t *flips;   // 4 x padded/8: FhtKacRotator sign flips
+  uint32_t rec_words, padded, trunc, ncl;
+  float fht_scale;        // 1 / sqrt(trunc)
+  double t_const;         // quant::faster_config(padded, 4).t_const
+};
+
+struct SlimQArgs {
+  const float *queries;   // nq x dim (device)
+  uint32_t nq, k;
+  uint32_t pool_cap;      // SearchBuffer capacity = ef_ (setEf, hnswalg_slimq.h:346-349)
+  uint32_t hash_slots;    // expanded-node set (LDS), power of two
+  uint32_t select_mask, grid;
+  uint64_t *out_labels;   // nq x k, the reference's heap-array order (hnswalg_slimq.h:1921-1923); ~0 beyond count
+  float *out_dists;       // nq x k exact distances of those entries
+  uint32_t *out_counts;   // nq: entries found (<= k)
+  uint32_t *stats;        // nq x 4 {expansions, estimates, pool inserts, revisits}   (nullable)
+  uint32_t *status;       // nq
+  uint32_t *counters;     // [0] expanded-set overflows
+};
+
+size_t slimq_lds_bytes(uint32_t dim, uint32_t padded, uint32_t ncl, uint32_t k, uint32_t hash_slots);
+bool slimq_supported(uint32_t pool_cap);
+hipError_t launch_slimq(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, hipStream_t stream);
+
+}  // namespace hs

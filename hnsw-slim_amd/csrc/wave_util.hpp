@@ -1,0 +1,85 @@
+// wave_util.hpp -- wavefront-level device helpers shared by beam_search.hip and slimq_search.hip (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "dist_recipe.hpp"
+
+namespace hs {
+
+// ---- wave helpers -------------------------------------------------------------------------------
+// One wavefront per workgroup: LDS operations of a wave execute in issue order, so lanes see each other's
+// LDS writes without s_barrier; all that is needed is that the COMPILER keeps the order.  (__syncthreads()
+// would also drain vmcnt, i.e. stall on every global load still in flight -- the adjacency / row reads this
+// kernel deliberately keeps outstanding while it works on the LDS heap.)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+// whole-wave shift right by one lane (DPP wave_shr:1, a single VALU op on GFX9); lane 0 receives `carry`
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t carry, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+// DPP move within a row of 16 lanes (row_shr / row_shl): one VALU op, no LDS round trip.  Lanes whose
+// source falls outside the row keep their own value; callers only consume in-row results.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+
+// Minimum of v over the wave without touching LDS: inclusive min-scan inside each row of 16 lanes with DPP
+// row_shr, then the four row results (lanes 15/31/47/63) are combined through SGPRs.
+__device__ __forceinline__ float wave_min_f32(float v) {
+  const uint32_t inf = __float_as_uint(FLT_MAX);
+#define HS_SHR_MIN(ctrl) v = fminf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)__float_as_uint(v), ctrl, 0xf, 0xf, false)))
+  HS_SHR_MIN(0x111);  // row_shr:1
+  HS_SHR_MIN(0x112);  // row_shr:2
+  HS_SHR_MIN(0x114);  // row_shr:4
+  HS_SHR_MIN(0x118);  // row_shr:8
+#undef HS_SHR_MIN
+  const uint32_t b = __float_as_uint(v);
+  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __uint_as_float(__builtin_amdgcn_readlane(b, 31));
+  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __uint_as_float(__builtin_amdgcn_readlane(b, 63));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
+template <int METRIC>
+__device__ __forceinline__ float lane4_reduce(const float (&acc)[4], int sub, bool &owner) {
+  if (METRIC == METRIC_L2) {
+    // TmpRes[0] + TmpRes[1] + ... + TmpRes[15], left to right (space_l2.h:49-51)
+    float r = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const float p = dpp_f<0x111>(r);  // row_shr:1 -- the running sum of the lane to the left (same 4-lane group)
+      if (sub == k) r = (((p + acc[0]) + acc[1]) + acc[2]) + acc[3];
+    }
+    owner = sub == 3;
+    return r;
+  } else {
+    // _mm512_reduce_add_ps: halves 16 -> 8 -> 4 -> 2 -> 1 (space_ip.h:197), then 1 - ip (:201-204)
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) h[i] = acc[i] + dpp_f<0x102>(acc[i]);  // row_shl:2: lane+2 of the group
+#pragma unroll
+    for (int i = 0; i < 4; i++) h[i] = h[i] + dpp_f<0x101>(h[i]);      // row_shl:1: lane+1
+    const float a0 = h[0] + h[2], a1 = h[1] + h[3];
+    const float ip = a0 + a1;
+    owner = sub == 0;
+    return 1.0f - ip;
+  }
+}
+template <int METRIC>
+__device__ __forceinline__ void step4(float (&acc)[4], const float4 &q4, const float4 &x4) {
+  const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+  const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+  if (METRIC == METRIC_L2) l2_step4(acc, q, x);
+  else ip_step4(acc, q, x);
+}
+
+
+}  // namespace hs

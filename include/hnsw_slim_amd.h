@@ -34,7 +34,7 @@ typedef enum {
   HS_ERR_CAPACITY = 7     /* a query outgrew even the fallback on-chip scratch */
 } hs_status;
 
-typedef enum { HS_KIND_HNSW = 0, HS_KIND_SLIM = 1 } hs_kind;   /* hnswalg.h:18 / hnswalg_slim.h:29 */
+typedef enum { HS_KIND_HNSW = 0, HS_KIND_SLIM = 1, HS_KIND_SLIMQ = 2 } hs_kind;   /* hnswalg.h:18 / hnswalg_slim.h:29 / hnswalg_slimq.h:41 */
 typedef enum { HS_METRIC_L2 = 0, HS_METRIC_IP = 1 } hs_metric; /* space_l2.h:208 / space_ip.h:342  */
 
 /* Which searchKnn overload a batch call reproduces. */
@@ -119,6 +119,26 @@ hs_status hs_search_check(hs_index *ix, void *stream);
  * mark_ep_visited selects the (q,k)/(q,k,filter) overloads' extra visited tag (hnswalg_slim.h:1796,1919). */
 hs_status hs_search_batch_raw(hs_index *ix, const float *queries, size_t nq, size_t k, int mode,
                               float *raw_dists, uint32_t *raw_ids, uint32_t *raw_sizes, uint32_t *stats);
+
+/* ---- HNSW-SlimQ: HierarchicalNSWSlimQ (hnswalg_slimq.h), the RaBitQ-quantised variant --------------------------
+ * hs_index_load(path, HS_KIND_SLIMQ, ..) parses saveIndex's format (hnswalg_slimq.h:1161-1313).  The search is
+ * searchKnn(query, k, tableint *result) (hnswalg_slimq.h:1810-1924): greedy descent and a SearchBuffer beam of
+ * capacity ef (hs_set_ef = setEf, :346-349) on ESTIMATED distances, every expanded node re-ranked with its exact
+ * distance to the raw row of setDataset() and kept in a k-bounded max-heap.  out_labels/out_dists are nq x k in the
+ * order the reference reads them out (the heap ARRAY, :1921-1923), ~0 / +inf beyond out_counts[q] entries (the
+ * reference leaves those slots undefined).  stats: nq x 4 {expansions, estimates, buffer inserts, revisits}.
+ * Float reductions that the reference runs through Eigen (alignment/width dependent order) are defined as
+ * left-to-right fp32 sums; see DESIGN.md "SlimQ". */
+hs_status hs_slimq_set_dataset(hs_index *ix, const float *base, size_t n, size_t dim);   /* setDataset, :303-305 */
+/* t_const of quant::faster_config (the reference draws it from std::random_device at load time, :1274-1276;
+ * default here: hs_rabitq_default_tconst(padded_dim, 1)). */
+hs_status hs_slimq_set_tconst(hs_index *ix, double t_const);
+double hs_slimq_get_tconst(const hs_index *ix);
+hs_status hs_slimq_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, uint64_t *out_labels,
+                                float *out_dists, uint32_t *out_counts, uint32_t *stats);
+/* device pointers + HIP stream; asynchronous, hs_search_check(ix, stream) reports capacity problems */
+hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, size_t k, uint64_t *d_out_labels,
+                                    float *d_out_dists, uint32_t *d_out_counts, uint32_t *d_stats, void *stream);
 
 /* ---- harness (CPU, not accelerated): produce index files in the reference's formats ------------ */
 /* HierarchicalNSW ctor + addPoint loop + saveIndex: hnswalg.h:85-159, 1248-1376, 748-779.

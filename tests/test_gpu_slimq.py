@@ -1,0 +1,123 @@
+"""HNSW-SlimQ on the GPU against the oracle restatement (oracle/hs_oracle_slimq.hpp), through the C ABI.
+
+Both sides read the same SlimQ index file (written by the product's CPU harness hs_convert_slimq) and use the same
+t_const.  Everything is compared exactly: the k-heap array (labels, exact distances, order), the number of entries
+and the traversal counters {expansions, estimates, buffer inserts, revisits} -- the counters only agree when every
+estimated distance, every SearchBuffer decision and every tie was taken the same way.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from hsutil import Oracle, load_product, sift_like
+
+pytestmark = pytest.mark.gpu
+
+
+def kmeans(x, k, seed=0, rounds=4):
+    rng = np.random.default_rng(seed)
+    cen = x[rng.choice(x.shape[0], k, replace=False)].copy()
+    for _ in range(rounds):
+        d = (x * x).sum(1)[:, None] - 2 * x @ cen.T + (cen * cen).sum(1)[None]
+        a = d.argmin(1)
+        for c in range(k):
+            if (a == c).any():
+                cen[c] = x[a == c].mean(0)
+    return cen
+
+
+@pytest.fixture(scope="module")
+def env(tmp_path_factory):
+    return load_product(), Oracle(), tmp_path_factory.mktemp("slimq")
+
+
+def build(P, tmp, name, base, metric, ncl, **slim):
+    d = base.shape[1]
+    h, s, sq = (str(tmp / f"{name}.{e}") for e in ("hnsw", "slim", "slimq"))
+    P.build_hnsw(base, h, metric=metric, M=16, ef_construction=100, threads=8)
+    P.convert_slim(h, s, d, metric=metric, threads=8, **slim)
+    P.convert_slimq(s, metric, d, kmeans(base, ncl), sq, threads=8)
+    return sq
+
+
+def check(P, O, path, base, q, metric, k, efs, t_const=None):
+    d = base.shape[1]
+    ix = P.Index(path, P.HS_KIND_SLIMQ, d, metric=metric)
+    ix.slimq_set_dataset(base)
+    if t_const is not None:
+        ix.slimq_set_tconst(t_const)
+    ox = O.load_slimq(path)
+    for ef in efs:
+        ix.set_ef(ef)
+        ox.set(ef, ix.slimq_tconst(), base)
+        got = ix.slimq_search(q, k, want_stats=True)
+        ref = ox.search(q, k, threads=8)
+        assert np.array_equal(got["stats"].astype(np.uint64), ref["counters"]), f"traversal differs at ef={ef}"
+        assert np.array_equal(got["cnt"], ref["counts"])
+        assert np.array_equal(got["labels"], ref["labels"]), f"labels differ at ef={ef}"
+        assert np.array_equal(got["dists"].view(np.uint32), ref["dists"].view(np.uint32))
+    return ix, ox
+
+
+def test_slimq_d128_l2(env):
+    P, O, tmp = env
+    x = sift_like(6000 + 300, 128, seed=11, n_clusters=48)
+    base, q = x[:6000], x[6000:]
+    path = build(P, tmp, "d128", base, 0, 16)
+    ix, ox = check(P, O, path, base, q, 0, 10, (10, 40, 64, 100, 200, 400))
+    # sanity: the quantised beam + exact re-rank finds the true neighbours
+    gt = O.brute_force(0, base, q, 10)
+    ix.set_ef(200)
+    got = ix.slimq_search(q, 10)["labels"]
+    rec = np.mean([len(set(got[i].tolist()) & set(gt[i].tolist())) / 10 for i in range(q.shape[0])])
+    assert rec > 0.9
+
+
+def test_slimq_integer_ties(env):
+    """Small integer coordinates: many equal exact distances (heap ties) and equal estimates."""
+    P, O, tmp = env
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 4, (3000, 64)).astype(np.float32)
+    q = rng.integers(0, 4, (200, 64)).astype(np.float32)
+    path = build(P, tmp, "int64", base, 0, 4)
+    check(P, O, path, base, q, 0, 10, (10, 50, 128))
+    check(P, O, path, base, q, 0, 1, (20,))
+    check(P, O, path, base, q, 0, 100, (100,))
+
+
+def test_slimq_d96_padded_rotator(env):
+    """dim 96 -> padded 128, truncated Hadamard 64 + Kac walk; runtime-length sign codes."""
+    P, O, tmp = env
+    x = sift_like(4000 + 200, 96, seed=3, n_clusters=32)
+    base, q = x[:4000], x[4000:]
+    path = build(P, tmp, "d96", base, 0, 8)
+    check(P, O, path, base, q, 0, 10, (30, 100))
+
+
+def test_slimq_d768_ip(env):
+    P, O, tmp = env
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2500 + 100, 768)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    base, q = x[:2500], x[2500:]
+    path = build(P, tmp, "d768", base, 1, 4)
+    check(P, O, path, base, q, 1, 10, (50,), t_const=88.0)
+
+
+def test_slimq_threshold_level_and_errors(env):
+    P, O, tmp = env
+    x = sift_like(5000 + 100, 128, seed=21, n_clusters=32)
+    base, q = x[:5000], x[5000:]
+    path = build(P, tmp, "thr", base, 0, 16, threshold_level=1)
+    ix, _ = check(P, O, path, base, q, 0, 10, (60,))
+    ix.set_ef(600)
+    with pytest.raises(P.HsError) as e:
+        ix.slimq_search(q, 10)
+    assert e.value.status == P.HS_ERR_UNSUPPORTED
+    with pytest.raises(P.HsError):
+        ix.search_pq(q, 10)
+    fresh = P.Index(path, P.HS_KIND_SLIMQ, 128)
+    with pytest.raises(P.HsError) as e:
+        fresh.slimq_search(q, 10)   # no dataset yet
+    assert e.value.status == P.HS_ERR_INVALID
