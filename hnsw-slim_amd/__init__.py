@@ -290,5 +290,11 @@ class Index:
                                          d_counts.data_ptr() if d_counts is not None else None,
                                          d_stats.data_ptr() if d_stats is not None else None, stream))
 
+    def slimq_search_dev(self, d_queries, k, d_labels, d_dists, d_counts, d_stats=None, stream=0):
+        """Device tensors (labels int64 nq x k, dists f32 nq x k, counts int32 nq) + HIP stream; asynchronous."""
+        _check(lib().hs_slimq_search_batch_dev(self._h, d_queries.data_ptr(), d_queries.shape[0], k, d_labels.data_ptr(),
+                                               d_dists.data_ptr(), d_counts.data_ptr(),
+                                               d_stats.data_ptr() if d_stats is not None else None, stream))
+
     def check(self, stream=0):
         _check(lib().hs_search_check(self._h, stream))

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""HNSW-SlimQ (RaBitQ) at size: parity against the oracle on a query sample + throughput / recall sweep.
+Usage: slimq_config.py sift|cohere [n]
+  sift   : the bench's SIFT-1M-like data, d=128 L2  (same graph as the fp32 bench line, quantised)
+  cohere : COHERE-1M-like, d=768 inner product on unit vectors (BASELINE.json configs[4])"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from hsutil import sift_like, headline_data, load_product, Oracle
+from bench import recall_at_k
+hs = load_product()
+which = sys.argv[1]
+if which == "sift":
+    n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 128, 10000, 0
+    gen = lambda m, seed: headline_data(m, d, seed)
+else:
+    n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 768, 1000, 1
+    def gen(m, seed):
+        x = sift_like(m, d, seed, n_clusters=2048, rank=32, sigma_sub=40.0, sigma_iso=3.0, integer=False, centre_lo=-60, centre_hi=60)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
+dev = torch.device("cuda", 0)
+bt = torch.from_numpy(base).to(dev); qt = torch.from_numpy(q).to(dev)
+# exact ground truth on the GPU (plumbing): L2 or inner product
+out = []
+bn = (bt * bt).sum(1)
+for s0 in range(0, nq, 512):
+    sc = qt[s0:s0 + 512] @ bt.T
+    dist = bn[None, :] - 2.0 * sc if metric == 0 else -sc
+    out.append(torch.topk(dist, 10, dim=1, largest=False).indices)
+gt = torch.cat(out).cpu().numpy(); del out, bn
+# 16 centroids by a few Lloyd rounds on a sample (the reference takes them from a k-means script: hnsw_slimq_strategy.h:101-106)
+rng = np.random.default_rng(0)
+samp = bt[torch.from_numpy(rng.choice(n, min(n, 200_000), replace=False)).to(dev)]
+cen = samp[:16].clone()
+for _ in range(8):
+    a = torch.cdist(samp, cen).argmin(1)
+    for c in range(16):
+        m = a == c
+        if m.any(): cen[c] = samp[m].mean(0)
+cen = cen.cpu().numpy(); del samp, bt
+with tempfile.TemporaryDirectory() as tmp:
+    hp, sp, qp = (os.path.join(tmp, f) for f in ("h.bin", "s.bin", "q.bin"))
+    t0 = time.time(); hs.build_hnsw(base, hp, metric=metric, M=16, ef_construction=200, threads=64); tb = time.time() - t0
+    t0 = time.time(); hs.convert_slim(hp, sp, d, metric=metric, threads=64); tc = time.time() - t0
+    t0 = time.time(); hs.convert_slimq(sp, metric, d, cen, qp, threads=64); tq = time.time() - t0
+    print(f"build {tb:.0f}s convert {tc:.0f}s quantise {tq:.0f}s  slim {os.path.getsize(sp)/1e6:.0f} MB slimq {os.path.getsize(qp)/1e6:.0f} MB", flush=True)
+    ix = hs.Index(qp, hs.HS_KIND_SLIMQ, d, metric=metric)
+    ox = Oracle().load_slimq(qp)
+ix.slimq_set_dataset(base)
+print("device bytes", ix.info()["device_bytes"], "t_const", ix.slimq_tconst(), flush=True)
+lab = torch.empty((nq, 10), dtype=torch.int64, device=dev); dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+cnt = torch.empty((nq,), dtype=torch.int32, device=dev); st = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+s = torch.cuda.current_stream().cuda_stream
+rec_bytes = 16 + (d + 63) // 64 * 8
+for ef in (32, 64, 96, 128, 192, 256, 384, 512):
+    ix.set_ef(ef); ox.set(ef, ix.slimq_tconst(), base)
+    for _ in range(2):
+        ix.slimq_search_dev(qt, 10, lab, dd, cnt, st, s); ix.check(s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ix.slimq_search_dev(qt, 10, lab, dd, cnt, None, s)
+    e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 5
+    L = lab.cpu().numpy().astype(np.uint64); S = st.cpu().numpy().astype(np.int64)
+    t0 = time.time(); want = ox.search(q[:200], 10, threads=32); tcpu = time.time() - t0
+    same = bool(np.array_equal(L[:200], want["labels"])) and bool(np.array_equal(S[:200], want["counters"].astype(np.int64)))
+    by = S[:, 1] * rec_bytes + S[:, 0] * (4 * d + 4 * 32)   # estimates x record + expansions x (raw row + adjacency tile)
+    print(f"ef={ef}: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} hops={S[:,0].mean():.0f} est={S[:,1].mean():.0f} ins={S[:,2].mean():.0f} "
+          f"revisit={S[:,3].mean():.0f} alg_GB/s={by.sum()/ms/1e6:.0f} oracle_match_first200={same} oracle_32thr_qps={200/tcpu:.0f}", flush=True)
