@@ -24,7 +24,7 @@ EXPORTS = [
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
     "hs_build_hnsw", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
-    "hs_slimq_search_batch", "hs_slimq_search_batch_dev",
+    "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug",
 ]
 
 
@@ -86,6 +86,8 @@ def lib():
     L.hs_slimq_get_tconst.argtypes = [vp]
     L.hs_slimq_search_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
     L.hs_slimq_search_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.hs_slimq_trace.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+    L.hs_slimq_prepare_debug.argtypes = [vp, vp, sz, vp]
     L.hs_rabitq_rotate.argtypes = [sz, vp, vp, sz, vp]
     L.hs_rabitq_quantize_data.argtypes = [sz, ci, vp, sz, vp, vp, vp]
     L.hs_rabitq_prepare_query.argtypes = [sz, ctypes.c_double, vp, sz, vp, vp]
@@ -289,6 +291,22 @@ class Index:
                                          d_dists.data_ptr() if d_dists is not None else None,
                                          d_counts.data_ptr() if d_counts is not None else None,
                                          d_stats.data_ptr() if d_stats is not None else None, stream))
+
+    def slimq_prepare_debug(self, queries, padded, ncl):
+        """dict(rq, q3, g_add, planes) as the kernel computed them."""
+        q = np.ascontiguousarray(queries, np.float32)
+        row = padded + 3 + ncl + padded // 8
+        out = np.empty((q.shape[0], row), np.float32)
+        _check(lib().hs_slimq_prepare_debug(self._h, q.ctypes.data, q.shape[0], out.ctypes.data))
+        pl = np.ascontiguousarray(out[:, padded + 3 + ncl:]).view(np.uint64)
+        return dict(rq=out[:, :padded].copy(), q3=out[:, padded:padded + 3].copy(), g_add=out[:, padded + 3:padded + 3 + ncl].copy(), planes=pl)
+
+    def slimq_trace(self, queries, k, cap=4096):
+        q = np.ascontiguousarray(queries, np.float32)
+        tr = np.empty((q.shape[0], cap), np.uint32)
+        st = np.empty((q.shape[0], 4), np.uint32)
+        _check(lib().hs_slimq_trace(self._h, q.ctypes.data, q.shape[0], k, tr.ctypes.data, cap, st.ctypes.data))
+        return tr, st
 
     def slimq_search_dev(self, d_queries, k, d_labels, d_dists, d_counts, d_stats=None, stream=0):
         """Device tensors (labels int64 nq x k, dists f32 nq x k, counts int32 nq) + HIP stream; asynchronous."""

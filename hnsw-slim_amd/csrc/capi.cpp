@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -80,6 +81,7 @@ struct hs_index {
   // per-stream scratch (grow-only): calls on different HIP streams may be in flight together
   struct StreamWs {
     DevBuf<uint32_t> spill;             // visited-set tier 2, nq x kSpillSlots
+    DevBuf<uint32_t> prep;              // SlimQ: per-query preparation records
     DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, tier-2 spills}
     size_t last_nq = 0;
   };
@@ -101,11 +103,14 @@ struct hs_index {
   DevBuf<uint8_t> wexcl;               // deleted | !allowed of the current filtered call
   // HNSW-SlimQ (kind == HS_KIND_SLIMQ): RaBitQ records, rotated centroids, rotator flips; `vec` then holds the
   // dataset rows of hs_slimq_set_dataset()
-  DevBuf<uint32_t> q_rec;
+  DevBuf<uint32_t> q_rec, q_ftile, q_uptile;
   DevBuf<float> q_cent;
   DevBuf<uint8_t> q_flips;
   DevSlimQ sq{};
   bool has_dataset = false;
+  float *prep_ptr = nullptr;       // debug: rotated queries of the next launch (unused by the ABI entries)
+  uint32_t *trace_ptr = nullptr;   // hs_slimq_trace only
+  uint32_t trace_cap = 0;
 };
 
 static uint32_t next_pow2(uint32_t v) {
@@ -235,16 +240,71 @@ static hs_status load_slimq(const char *path, int metric, size_t dim, int device
     memcpy(r + 3, &q.factors[i * 3 + 2], 4);
     memcpy(r + 4, &q.code[i * nblk], 8 * nblk);
   }
+  // fused level-0 tiles (see slimq_engine.hpp): 288 GB of HBM buys one dependent access per expansion.
+  // HS_SLIMQ_FUSED=0 (debug/test knob) keeps the CSR + record-array layout that wide graphs (degree > 64) fall back to.
+  const char *fused_env = getenv("HS_SLIMQ_FUSED");
+  const bool fused = !(fused_env && fused_env[0] == '0');
+  const uint32_t stride = fused ? ix->dev.tile_stride : 0;
+  std::vector<uint32_t> ft;
+  if (stride) {
+    ft.assign((size_t)q.count * stride * rw, 0u);
+    for (size_t i = 0; i < q.count; i++) {
+      uint32_t *row = &ft[i * stride * rw];
+      const uint32_t deg = p.row_ptr0[i + 1] - p.row_ptr0[i];
+      for (uint32_t j = 0; j < stride; j++) {
+        uint32_t *r = row + (size_t)j * rw;
+        if (j < deg) {
+          const uint32_t nb = p.cols[p.row_ptr0[i] + j];
+          memcpy(r, &rec[(size_t)nb * rw], 4 * rw);
+          r[3] = nb;
+        } else {
+          r[3] = 0xFFFFFFFFu;
+        }
+      }
+    }
+  }
+  // fused upper-level tiles: slot up_base[i] + l - 1 holds level l of node i
+  uint32_t up_stride = 0;
+  std::vector<uint32_t> ut;
+  {
+    size_t max_up = 0;
+    for (size_t t = 0; t + 1 < p.up_ptr.size(); t++) max_up = std::max<size_t>(max_up, p.up_ptr[t + 1] >= p.up_ptr[t] ? p.up_ptr[t + 1] - p.up_ptr[t] : 0);
+    if (fused && !p.up_ptr.empty() && max_up <= 64) {
+      up_stride = std::max<uint32_t>(16, (uint32_t)((max_up + 15) / 16 * 16));
+      const uint32_t urw = rw + 4;
+      ut.assign(p.up_ptr.size() * (size_t)up_stride * urw, 0u);
+      for (size_t t = 0; t < p.up_ptr.size(); t++)
+        for (uint32_t j = 0; j < up_stride; j++) ut[(t * up_stride + j) * urw + 3] = 0xFFFFFFFFu;
+      for (size_t i = 0; i < q.count; i++) {
+        const uint32_t b = p.up_base[i];
+        if (b == PackedIndex::NONE) continue;
+        for (int l = 1; l <= q.level[i]; l++) {
+          const uint32_t s0 = p.up_ptr[b + l - 1], e0 = p.up_ptr[b + l];
+          for (uint32_t j = 0; j < e0 - s0; j++) {
+            const uint32_t nb = p.cols[s0 + j];
+            uint32_t *r = &ut[((size_t)(b + l - 1) * up_stride + j) * urw];
+            memcpy(r, &rec[(size_t)nb * rw], 4 * rw);
+            r[3] = nb;
+            r[rw] = p.up_base[nb];
+          }
+        }
+      }
+    }
+  }
   hipError_t e = ix->q_rec.upload(rec);
+  if (e == hipSuccess && up_stride) e = ix->q_uptile.upload(ut);
+  if (e == hipSuccess && stride) e = ix->q_ftile.upload(ft);
   if (e == hipSuccess) e = ix->q_cent.upload(q.centroids);
   if (e == hipSuccess) e = ix->q_flips.upload(q.rot.flip);
   if (e != hipSuccess) { delete ix; return fail(HS_ERR_DEVICE, std::string("SlimQ upload: ") + hipGetErrorString(e)); }
   DevSlimQ &d = ix->sq;
-  d.rec = ix->q_rec.p; d.raw = nullptr; d.cent = ix->q_cent.p; d.flips = ix->q_flips.p;
+  d.rec = ix->q_rec.p; d.ftile = stride ? ix->q_ftile.p : nullptr; d.raw = nullptr;
+  d.uptile = up_stride ? ix->q_uptile.p : nullptr; d.up_stride = up_stride;
+  d.ep_base = q.count ? p.up_base[q.enterpoint] : 0xFFFFFFFFu; d.cent = ix->q_cent.p; d.flips = ix->q_flips.p;
   d.rec_words = rw; d.padded = (uint32_t)q.padded; d.trunc = (uint32_t)q.rot.trunc; d.ncl = (uint32_t)q.num_cluster;
   d.fht_scale = q.rot.fac;
   d.t_const = rq_default_tconst(q.padded, 1);
-  ix->info.device_bytes += rec.size() * 4 + q.centroids.size() * 4 + q.rot.flip.size();
+  ix->info.device_bytes += (rec.size() + ft.size() + ut.size()) * 4 + q.centroids.size() * 4 + q.rot.flip.size();
   *out = ix;
   return HS_OK;
 }
@@ -500,6 +560,11 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   a.hash_slots = std::min(a.hash_slots, kSlimQMaxHash);
   a.out_labels = d_out_labels; a.out_dists = d_out_dists; a.out_counts = d_out_counts; a.stats = d_stats;
   a.status = w->status.p;
+  a.trace = ix->trace_ptr; a.trace_cap = ix->trace_cap;
+  const uint32_t pw = slimq_prep_words(ix->sq.ncl, ix->sq.padded);
+  HIP_TRY(w->prep.ensure(nq * (size_t)pw));
+  HIP_TRY(launch_slimq_prep(ix->sq, (uint32_t)ix->info.dim, ix->info.metric, d_queries, (uint32_t)nq, w->prep.p, ix->prep_ptr, stream));
+  a.prep = w->prep.p;
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p;
   HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
   if (a.hash_slots < kSlimQMaxHash) {
@@ -507,6 +572,59 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
     a.counters = w->counters.p + 8;
     HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
   }
+  return HS_OK;
+}
+
+// Parity/debug entry: the query preparation as the kernel computed it (rotation, split query, centroid table).
+hs_status hs_slimq_prepare_debug(hs_index *ix, const float *queries, size_t nq, float *out) {
+  if (!ix || !queries || !out) return fail(HS_ERR_INVALID, "null argument");
+  if (ix->info.kind != HS_KIND_SLIMQ) return fail(HS_ERR_INVALID, "not a SlimQ index");
+  if (nq == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t P = ix->sq.padded, ncl = ix->sq.ncl, npl = P / 8, row = P + 3 + ncl + npl;
+  const uint32_t pw = slimq_prep_words(ix->sq.ncl, ix->sq.padded);
+  DevBuf<float> dq, dy;
+  DevBuf<uint32_t> dp;
+  HIP_TRY(dq.alloc(nq * ix->info.dim)); HIP_TRY(dy.alloc(nq * P)); HIP_TRY(dp.alloc(nq * (size_t)pw));
+  HIP_TRY(hipMemcpy(dq.p, queries, nq * ix->info.dim * 4, hipMemcpyHostToDevice));
+  HIP_TRY(launch_slimq_prep(ix->sq, (uint32_t)ix->info.dim, ix->info.metric, dq.p, (uint32_t)nq, dp.p, dy.p, nullptr));
+  std::vector<float> y(nq * P);
+  std::vector<uint32_t> pr(nq * (size_t)pw);
+  HIP_TRY(hipMemcpy(y.data(), dy.p, y.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(pr.data(), dp.p, pr.size() * 4, hipMemcpyDeviceToHost));
+  const size_t poff = (4 + ncl + 1) & ~size_t(1);
+  for (size_t i = 0; i < nq; i++) {
+    float *o = out + i * row;
+    const uint32_t *r = &pr[i * pw];
+    memcpy(o, &y[i * P], P * 4);
+    memcpy(o + P, r, 12);
+    memcpy(o + P + 3, r + 4, ncl * 4);
+    memcpy(o + P + 3 + ncl, r + poff, npl * 4);
+  }
+  return HS_OK;
+}
+
+// Parity/debug entry: the sequence of SearchBuffer pops of each query (node id, bit 31 = already expanded).
+hs_status hs_slimq_trace(hs_index *ix, const float *queries, size_t nq, size_t k, uint32_t *out_trace, size_t trace_cap,
+                         uint32_t *stats) {
+  if (!ix || !queries || !out_trace || trace_cap == 0) return fail(HS_ERR_INVALID, "null argument");
+  if (nq == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  DevBuf<float> dq, dd;
+  DevBuf<uint64_t> dl;
+  DevBuf<uint32_t> dc, ds, dt;
+  HIP_TRY(dq.alloc(nq * ix->info.dim)); HIP_TRY(dl.alloc(nq * k)); HIP_TRY(dd.alloc(nq * k)); HIP_TRY(dc.alloc(nq));
+  HIP_TRY(ds.alloc(nq * 4)); HIP_TRY(dt.alloc(nq * trace_cap));
+  HIP_TRY(hipMemcpy(dq.p, queries, nq * ix->info.dim * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dt.p, 0xFF, nq * trace_cap * 4));
+  ix->trace_ptr = dt.p; ix->trace_cap = (uint32_t)trace_cap;
+  hs_status s = hs_slimq_search_batch_dev(ix, dq.p, nq, k, dl.p, dd.p, dc.p, ds.p, nullptr);
+  ix->trace_ptr = nullptr; ix->trace_cap = 0;
+  if (s != HS_OK) return s;
+  s = hs_search_check(ix, nullptr);
+  if (s != HS_OK) return s;
+  HIP_TRY(hipMemcpy(out_trace, dt.p, nq * trace_cap * 4, hipMemcpyDeviceToHost));
+  if (stats) HIP_TRY(hipMemcpy(stats, ds.p, nq * 16, hipMemcpyDeviceToHost));
   return HS_OK;
 }
 

@@ -24,8 +24,10 @@ struct LessD { HS_HD bool operator()(const Pair &a, const Pair &b) const { retur
 struct GreaterD { HS_HD bool operator()(const Pair &a, const Pair &b) const { return a.d > b.d; } };
 
 // std::__push_heap
-template <class P, class C>
-HS_HD void sift_up(P *a, long hole, long top, Pair v, C comp) {
+// `A a` is a pointer to Pair-like elements or any handle with a[i] convertible to Pair and assignable from Pair
+// (slimq_search.hip keeps a small heap in registers, one element per lane).
+template <class A, class C>
+HS_HD void sift_up(A a, long hole, long top, Pair v, C comp) {
   long parent = (hole - 1) / 2;
   while (hole > top && comp(a[parent], v)) {
     a[hole] = a[parent];
@@ -35,14 +37,14 @@ HS_HD void sift_up(P *a, long hole, long top, Pair v, C comp) {
   a[hole] = v;
 }
 // std::push_heap on a[0..n): a[n-1] is the new element.
-template <class P, class C>
-HS_HD void push_heap(P *a, long n, C comp) {
+template <class A, class C>
+HS_HD void push_heap(A a, long n, C comp) {
   Pair v = a[n - 1];
   sift_up(a, n - 1, 0, v, comp);
 }
 // std::__adjust_heap
-template <class P, class C>
-HS_HD void adjust_heap(P *a, long hole, long len, Pair v, C comp) {
+template <class A, class C>
+HS_HD void adjust_heap(A a, long hole, long len, Pair v, C comp) {
   const long top = hole;
   long child = hole;
   while (child < (len - 1) / 2) {
@@ -59,8 +61,8 @@ HS_HD void adjust_heap(P *a, long hole, long len, Pair v, C comp) {
   sift_up(a, hole, top, v, comp);
 }
 // std::pop_heap on a[0..n): afterwards a[n-1] holds the old root and a[0..n-1) is a heap.
-template <class P, class C>
-HS_HD void pop_heap(P *a, long n, C comp) {
+template <class A, class C>
+HS_HD void pop_heap(A a, long n, C comp) {
   if (n > 1) {
     Pair v = a[n - 1];
     a[n - 1] = a[0];

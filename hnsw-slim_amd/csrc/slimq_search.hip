@@ -38,15 +38,13 @@ static constexpr uint32_t kChecked = 0x80000000u;
 
 __host__ __device__ inline uint32_t al16(uint32_t x) { return (x + 15u) & ~15u; }
 
-struct SlimQLds { uint32_t off_q, off_y, off_u, off_planes, off_red, off_hash, off_heap, off_pend, off_pd, total; };
+struct SlimQLds { uint32_t off_q, off_planes, off_red, off_hash, off_heap, off_pend, off_pd, total; };
 __host__ __device__ inline SlimQLds slimq_layout(uint32_t dim, uint32_t padded, uint32_t ncl, uint32_t k, uint32_t hash_slots) {
   SlimQLds l;
   uint32_t o = 0;
   l.off_q = o; o += al16(dim * 4);
-  l.off_y = o; o += al16(padded * 4);
-  l.off_u = o; o += al16(padded * 4);
   l.off_planes = o; o += al16(padded / 64 * 4 * 8);
-  l.off_red = o; o += al16((ncl + 4) * 4);   // [0] sumq [1] |q|^2 [2] <q,u> [3] |u|^2 [4+c] g_add of cluster c
+  l.off_red = o; o += al16(ncl * 4);         // g_add of cluster c
   l.off_hash = o; o += al16(hash_slots * 4);
   l.off_heap = o; o += al16((k + 1) * 8);
   l.off_pend = o; o += 64;
@@ -77,58 +75,101 @@ __device__ __forceinline__ void set_add(uint32_t *tab, uint32_t mask, uint32_t i
 }
 
 // ---- SearchBuffer in registers --------------------------------------------------------------------------------
+// Rank r lives in lane r % 64 of slot r / 64.  Ranks at or beyond `size` hold key = +inf, val = 0xFFFFFFFF (reads as
+// "checked"), so neither the position count nor the unchecked scan needs a size mask; entries pushed beyond the
+// capacity are masked by rank < cap in the unchecked scan and can never compare below a candidate that passed
+// is_full().  All control flow here is wave-uniform (scalar branches): the kernel is VALU-issue bound, and a slot
+// that an insertion does not touch costs no vector instruction.
+static constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 template <int S>
-__device__ __forceinline__ float pool_key_at(const float (&key)[S], uint32_t r) {
-  float v = 0.f;
-#pragma unroll
-  for (int s = 0; s < S; s++)
-    if ((r >> 6) == (uint32_t)s) v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(key[s]), r & 63));
-  return v;
-}
-// insert(): lower-bound position, shift the tail up by one, drop what falls beyond the capacity (:112-119)
+struct PoolState {
+  uint32_t size, cap, cur;   // cur = rank of the first unchecked entry (SearchBuffer::cur_), kNoRank when none
+  float last;                // key at rank cap-1 once size == cap, else +inf: is_full(d) == (d > last)
+};
+// insert(): lower-bound position, shift the tail up by one (:112-119)
 template <int S>
-__device__ __forceinline__ void pool_insert(float (&key)[S], uint32_t (&val)[S], uint32_t &size, uint32_t cap, float d,
-                                            uint32_t id, int lane) {
+__device__ __forceinline__ void pool_insert(float (&key)[S], uint32_t (&val)[S], PoolState<S> &p, float d, uint32_t id, int lane) {
   uint32_t pos = 0;
 #pragma unroll
-  for (int s = 0; s < S; s++) pos += __popcll(__ballot((uint32_t)(lane + 64 * s) < size && key[s] < d));
+  for (int s = 0; s < S; s++) pos += __popcll(__ballot(key[s] < d));
+  const uint32_t sp = pos >> 6, lp = pos & 63;
   uint32_t carry_k = 0, carry_v = 0;
 #pragma unroll
   for (int s = 0; s < S; s++) {
+    if ((uint32_t)s < sp) continue;
     const uint32_t kb = __float_as_uint(key[s]);
-    const uint32_t last_k = __builtin_amdgcn_readlane(kb, 63), last_v = __builtin_amdgcn_readlane(val[s], 63);
+    uint32_t last_k = 0, last_v = 0;
+    if (s + 1 < S) { last_k = __builtin_amdgcn_readlane(kb, 63); last_v = __builtin_amdgcn_readlane(val[s], 63); }
     const uint32_t up_k = wave_shr1(carry_k, kb), up_v = wave_shr1(carry_v, val[s]);
-    const uint32_t r = lane + 64 * s;
-    key[s] = r > pos ? __uint_as_float(up_k) : (r == pos ? d : key[s]);
-    val[s] = r > pos ? up_v : (r == pos ? id : val[s]);
+    if ((uint32_t)s == sp) {
+      key[s] = (uint32_t)lane > lp ? __uint_as_float(up_k) : ((uint32_t)lane == lp ? d : key[s]);
+      val[s] = (uint32_t)lane > lp ? up_v : ((uint32_t)lane == lp ? id : val[s]);
+    } else {
+      key[s] = __uint_as_float(up_k);
+      val[s] = up_v;
+    }
     carry_k = last_k;
     carry_v = last_v;
   }
-  size = min(size + 1, cap);
+  p.size = min(p.size + 1, p.cap);
+  p.cur = min(p.cur, pos);
+  if (p.size == p.cap) {
+    const uint32_t sl = (p.cap - 1) >> 6, ll = (p.cap - 1) & 63;
+#pragma unroll
+    for (int s = 0; s < S; s++)
+      if ((uint32_t)s == sl) p.last = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(key[s]), ll));
+  }
 }
-// pop(): closest unchecked entry (cur_ is always the first unchecked rank, :126-134); false when none is left
+// pop(): the entry at cur_, then advance cur_ to the next unchecked rank (:126-134)
 template <int S>
-__device__ __forceinline__ bool pool_pop(uint32_t (&val)[S], uint32_t size, uint32_t &id, int lane) {
-  bool found = false;
+__device__ __forceinline__ uint32_t pool_pop(uint32_t (&val)[S], PoolState<S> &p, int lane) {
+  const uint32_t sc = p.cur >> 6, lc = p.cur & 63;
+  uint32_t id = 0, next = kNoRank;
 #pragma unroll
   for (int s = 0; s < S; s++) {
-    const unsigned long long m = found ? 0ull : __ballot((uint32_t)(lane + 64 * s) < size && !(val[s] & kChecked));
-    if (m) {
-      const int l = __ffsll((long long)m) - 1;
-      id = __builtin_amdgcn_readlane(val[s], l);
-      if (lane == l) val[s] |= kChecked;
-      found = true;
+    if ((uint32_t)s < sc || next != kNoRank) continue;
+    if ((uint32_t)s == sc) {
+      id = __builtin_amdgcn_readlane(val[s], lc);
+      if ((uint32_t)lane == lc) val[s] |= kChecked;
     }
+    unsigned long long m = __ballot((int)val[s] >= 0);
+    const int lim = (int)p.cap - 64 * s;               // ranks of this slot below the capacity
+    if (lim <= 0) m = 0ull;
+    else if (lim < 64) m &= (1ull << lim) - 1;
+    if ((uint32_t)s == sc) m &= lc == 63 ? 0ull : ~((2ull << lc) - 1);
+    if (m) next = 64u * s + (uint32_t)__ffsll((long long)m) - 1;
   }
-  return found;
+  p.cur = next;
+  return id;
 }
 
-// ---- estimator of one record (any lane, its own id) ----------------------------------------------------------
+// ---- k-bounded result heap in registers: element j lives in lane j (k < 64) -------------------------------------
+// Every lane runs the same (wave-uniform) sift code of heap_emul.hpp; element reads are v_readlane, writes a
+// lane-masked move -- a few cycles per step instead of an LDS round trip on one lane.
+struct RegHeap {
+  float &key;
+  uint32_t &id;
+  int lane;
+  struct Ref {
+    const RegHeap &h;
+    long j;
+    __device__ __forceinline__ operator Pair() const {
+      return Pair{__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.key), (int)j)), (uint32_t)__builtin_amdgcn_readlane(h.id, (int)j)};
+    }
+    __device__ __forceinline__ const Ref &operator=(const Pair &p) const {
+      if (h.lane == (int)j) { h.key = p.d; h.id = p.id; }
+      return *this;
+    }
+    __device__ __forceinline__ const Ref &operator=(const Ref &o) const { return *this = (Pair)o; }
+  };
+  __device__ __forceinline__ Ref operator[](long j) const { return Ref{*this, j}; }
+};
+
+// ---- estimator of one record (any lane, its own record) ------------------------------------------------------
+// r -> {f_add, f_rescale, cluster id, (f_error | neighbour id)} + sign code; h = the header, already loaded
 template <int NBLK>
-__device__ __forceinline__ float est_one(const DevSlimQ &sq, const uint64_t *planes, const float *gadd, float delta, float vl,
-                                         float k1, uint32_t id) {
-  const uint32_t *r = sq.rec + (size_t)id * sq.rec_words;
-  const uint4 h = *reinterpret_cast<const uint4 *>(r);
+__device__ __forceinline__ float est_rec(const DevSlimQ &sq, const uint64_t *planes, const float *gadd, float delta, float vl,
+                                         float k1, const uint32_t *r, const uint4 &h) {
   const uint64_t *code = reinterpret_cast<const uint64_t *>(r + 4);
   float ipq;
   if (NBLK > 0) {
@@ -145,9 +186,17 @@ __device__ __forceinline__ float est_one(const DevSlimQ &sq, const uint64_t *pla
   }
   return rq_est_dist(__uint_as_float(h.x), gadd[h.z], __uint_as_float(h.y), ipq, k1);
 }
+template <int NBLK>
+__device__ __forceinline__ float est_one(const DevSlimQ &sq, const uint64_t *planes, const float *gadd, float delta, float vl,
+                                         float k1, uint32_t id) {
+  const uint32_t *r = sq.rec + (size_t)id * sq.rec_words;
+  const uint4 h = *reinterpret_cast<const uint4 *>(r);
+  return est_rec<NBLK>(sq, planes, gadd, delta, vl, k1, r, h);
+}
 
 // ---- query preparation ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void flip_signs(float *y, const uint8_t *f, uint32_t n, int lane) {
+#pragma unroll 1
   for (uint32_t i = lane; i < n; i += 64)
     if ((f[i >> 3] >> (i & 7)) & 1) y[i] = -y[i];
 }
@@ -155,6 +204,7 @@ __device__ __forceinline__ void flip_signs(float *y, const uint8_t *f, uint32_t 
 __device__ __forceinline__ void fht_lds(float *y, uint32_t n, float scale, int lane) {
   for (uint32_t h = 1; h < n; h <<= 1) {
     wave_sync();
+#pragma unroll 1
     for (uint32_t t = lane; t < n / 2; t += 64) {
       const uint32_t j = ((t / h) * 2 * h) + (t % h);
       const float a = y[j], b = y[j + h];
@@ -163,6 +213,7 @@ __device__ __forceinline__ void fht_lds(float *y, uint32_t n, float scale, int l
     }
   }
   wave_sync();
+#pragma unroll 1
   for (uint32_t i = lane; i < n; i += 64) y[i] *= scale;
 }
 __device__ __forceinline__ void rotate_lds(const DevSlimQ &sq, float *y, int lane) {
@@ -181,6 +232,7 @@ __device__ __forceinline__ void rotate_lds(const DevSlimQ &sq, float *y, int lan
     flip_signs(y, sq.flips + r * nb, P, lane);
     fht_lds((r & 1) ? y + (P - T) : y, T, sq.fht_scale, lane);
     wave_sync();
+#pragma unroll 1
     for (uint32_t i = lane; i < P / 2; i += 64) {  // kacs_walk
       const float a = y[i], b = y[i + P / 2];
       y[i] = a + b;
@@ -188,8 +240,130 @@ __device__ __forceinline__ void rotate_lds(const DevSlimQ &sq, float *y, int lan
     }
   }
   wave_sync();
+#pragma unroll 1
   for (uint32_t i = lane; i < P; i += 64) y[i] *= 0.25f;
   wave_sync();
+}
+
+// Per-query preparation record in global memory (prep_words(ncl, padded) u32 words):
+//   [0] delta [1] vl [2] k1xsumq [3] -   [4 .. 4+ncl) g_add per cluster   [align 2] 4 bit planes per 64-dim block (u64)
+__host__ __device__ inline uint32_t prep_planes_off(uint32_t ncl) { return (4 + ncl + 1) & ~1u; }
+__host__ __device__ inline uint32_t prep_words_of(uint32_t ncl, uint32_t padded) { return (prep_planes_off(ncl) + padded / 64 * 8 + 3) & ~3u; }
+uint32_t slimq_prep_words(uint32_t ncl, uint32_t padded) { return prep_words_of(ncl, padded); }
+
+// One wavefront per query: rotation (rotator.hpp:370-423), SplitSingleQuery (query.hpp:112-156), centroid table
+// (hnswalg_slimq.h:1822-1848).  Kept out of the search kernel so that its registers and LDS are sized by the
+// traversal alone.
+template <int METRIC>
+__global__ void __launch_bounds__(64) slimq_prep_kernel(DevSlimQ sq, uint32_t dim, const float *queries, uint32_t nq,
+                                                        uint32_t *prep, float *dbg_y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const uint32_t P = sq.padded;
+  float *y = reinterpret_cast<float *>(smem);
+  float *u = y + P;
+  uint64_t *planes_lds = reinterpret_cast<uint64_t *>(u + P);
+  float *red = reinterpret_cast<float *>(planes_lds + P / 64 * 4);
+  float *gadd = red + 4;
+  const uint32_t pw = prep_words_of(sq.ncl, P);
+  for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+    wave_sync();
+#pragma unroll 1
+    for (uint32_t i = lane; i < P; i += 64) {
+      y[i] = i < dim ? queries[(size_t)qi * dim + i] : 0.f;
+    }
+    rotate_lds(sq, y, lane);
+
+    // Reductions, one per lane and all in one loop: sum(q') (= <q', 1>), |q'|^2 (= |q' - 0|^2) and per centroid
+    // |q' - c|^2 (L2) or <q', c> (IP).  Each is a strict left-to-right fp32 sum (the definition rabitq_host.hpp
+    // documents); x * 1 and x - 0 are exact, so the two query-only sums share the centroid loops' arithmetic.
+    // sqrt and division below must be the correctly rounded ones (plain sqrtf / operator/ under hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn maps to the NATIVE (1 ulp) square root in this ROCm.
+    for (uint32_t t0 = 0; t0 < 2 + sq.ncl; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      const bool live = t < 2 + sq.ncl, is_c = live && t >= 2;
+      const bool l2form = t == 1 || (is_c && METRIC == METRIC_L2);
+      const float4 *ce = reinterpret_cast<const float4 *>(sq.cent + (size_t)(is_c ? t - 2 : 0) * P);
+      const float cfill = t == 0 ? 1.f : 0.f;
+      float s = 0.f;
+      for (uint32_t i = 0; i < P; i += 16) {
+        float c[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float4 v = make_float4(cfill, cfill, cfill, cfill);
+          if (is_c) v = ce[(i >> 2) + j];
+          c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const float yv = y[i + j];
+          const float x = l2form ? yv - c[j] : yv;
+          const float m = x * (l2form ? x : c[j]);
+          s += m;
+        }
+      }
+      if (t == 0) red[0] = s;
+      else if (t == 1) red[1] = s;
+      else if (is_c) {
+        if (METRIC == METRIC_L2) {
+          const float nrm = __builtin_sqrtf(s);
+          gadd[t - 2] = nrm * nrm;        // get_bin_est: g_add = norm * norm (hnswalg_slimq.h:436)
+        } else {
+          gadd[t - 2] = -s;               // g_add = -<q', c>  (:423)
+        }
+      }
+    }
+    wave_sync();
+    const float nrm = __builtin_sqrtf(red[1]);
+    const float k1 = red[0] * (-0.5f);
+    // 4-bit scalar code of q' (1 sign bit + 3 magnitude bits), its bit planes, and u = code - 7.5
+    for (uint32_t b = 0; b < P / 64; b++) {
+      const float v = y[b * 64 + lane];
+      const float oa = fabsf(((v) / (nrm)));
+      int c = (int)(sq.t_const * (double)oa + 1e-5);
+      c = c >= 8 ? 7 : c;
+      if (v < 0.f) c = (~c) & 7;
+      c += v > 0.f ? 8 : 0;
+      u[b * 64 + lane] = (float)c + (-7.5f);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned long long m = __ballot((c >> j) & 1);
+        if (lane == 0) planes_lds[b * 4 + j] = __brevll(m);   // dimension i -> bit 63 - i%64
+      }
+    }
+    wave_sync();
+    {  // <q', u> on lane 0 and |u|^2 on lane 1, same loop
+      float s = 0.f;
+      for (uint32_t i = 0; i < P; i += 4) {
+        const float4 uv = *reinterpret_cast<const float4 *>(u + i), yv = *reinterpret_cast<const float4 *>(y + i);
+        s += (lane == 0 ? yv.x : uv.x) * uv.x;
+        s += (lane == 0 ? yv.y : uv.y) * uv.y;
+        s += (lane == 0 ? yv.z : uv.z) * uv.z;
+        s += (lane == 0 ? yv.w : uv.w) * uv.w;
+      }
+      if (lane < 2) red[2 + lane] = s;
+    }
+    wave_sync();
+    const float nq = __builtin_sqrtf(red[3]);
+    const float cos_sim = ((red[2]) / (nrm * nq));
+    const float delta = ((nrm) / (nq)) * cos_sim;
+    const float vl = delta * (-7.5f);
+    wave_sync();
+    uint32_t *o = prep + (size_t)qi * pw;
+    if (lane == 0) { o[0] = __float_as_uint(delta); o[1] = __float_as_uint(vl); o[2] = __float_as_uint(k1); o[3] = 0u; }
+    for (uint32_t i = lane; i < sq.ncl; i += 64) o[4 + i] = __float_as_uint(gadd[i]);
+    const uint32_t *plw = reinterpret_cast<const uint32_t *>(planes_lds);
+    for (uint32_t i = lane; i < P / 64 * 8; i += 64) o[prep_planes_off(sq.ncl) + i] = plw[i];
+    if (dbg_y)
+      for (uint32_t i = lane; i < P; i += 64) dbg_y[(size_t)qi * P + i] = y[i];
+  }
+}
+hipError_t launch_slimq_prep(const DevSlimQ &sq, uint32_t dim, int metric, const float *queries, uint32_t nq, uint32_t *prep,
+                             float *dbg_y, hipStream_t stream) {
+  const size_t lds = (size_t)sq.padded * 8 + sq.padded / 64 * 32 + (sq.ncl + 4) * 4 + 16;
+  if (metric == METRIC_L2) hipLaunchKernelGGL(slimq_prep_kernel<METRIC_L2>, dim3(nq), dim3(64), lds, stream, sq, dim, queries, nq, prep, dbg_y);
+  else hipLaunchKernelGGL(slimq_prep_kernel<METRIC_IP>, dim3(nq), dim3(64), lds, stream, sq, dim, queries, nq, prep, dbg_y);
+  return hipGetLastError();
 }
 
 template <int METRIC, int S, int NBLK>
@@ -197,86 +371,76 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   const int lane = threadIdx.x;
   const SlimQLds L = slimq_layout(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
-  float *y = reinterpret_cast<float *>(smem + L.off_y);
-  float *u = reinterpret_cast<float *>(smem + L.off_u);
-  uint64_t *planes = reinterpret_cast<uint64_t *>(smem + L.off_planes);
-  float *red = reinterpret_cast<float *>(smem + L.off_red);
-  float *gadd = red + 4;
+  uint64_t *planes_lds = reinterpret_cast<uint64_t *>(smem + L.off_planes);
+  float *gadd = reinterpret_cast<float *>(smem + L.off_red);
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem + L.off_hash);
   Pair *heap = reinterpret_cast<Pair *>(smem + L.off_heap);
   uint32_t *pend = reinterpret_cast<uint32_t *>(smem + L.off_pend);
   float *pd = reinterpret_cast<float *>(smem + L.off_pd);
   const uint32_t P = sq.padded, mask = a.hash_slots - 1;
+  const uint32_t *pr = a.prep + (size_t)qi * prep_words_of(sq.ncl, P);
 
   wave_sync();
+#pragma unroll 1
   for (uint32_t i = lane; i < ix.dim; i += 64) qv[i] = a.queries[(size_t)qi * ix.dim + i];
-  for (uint32_t i = lane; i < P; i += 64) y[i] = i < ix.dim ? a.queries[(size_t)qi * ix.dim + i] : 0.f;
+#pragma unroll 1
   for (uint32_t i = lane; i < a.hash_slots; i += 64) tab[i] = kNoneQ;
-  rotate_lds(sq, y, lane);
-
-  // reductions, one per lane: sum(q'), |q'|^2, and per centroid |q'-c|^2 (L2) or <q',c> (IP)
-  for (uint32_t t = lane; t < 2 + sq.ncl; t += 64) {
-    float s = 0.f;
-    if (t == 0) {
-      for (uint32_t i = 0; i < P; i++) s += y[i];
-      red[0] = s;
-    } else if (t == 1) {
-      for (uint32_t i = 0; i < P; i++) s += y[i] * y[i];
-      red[1] = s;
-    } else {
-      const float *ce = sq.cent + (size_t)(t - 2) * P;
-      if (METRIC == METRIC_L2) {
-        for (uint32_t i = 0; i < P; i++) { const float d = y[i] - ce[i]; s += d * d; }
-        const float nrm = __fsqrt_rn(s);
-        gadd[t - 2] = nrm * nrm;        // get_bin_est: g_add = norm * norm (hnswalg_slimq.h:436)
-      } else {
-        for (uint32_t i = 0; i < P; i++) s += y[i] * ce[i];
-        gadd[t - 2] = -s;               // g_add = -<q', c>  (:423)
-      }
-    }
+#pragma unroll 1
+  for (uint32_t i = lane; i < sq.ncl; i += 64) gadd[i] = __uint_as_float(pr[4 + i]);
+  const float delta = __uint_as_float(uni(pr[0])), vl = __uint_as_float(uni(pr[1])), k1 = __uint_as_float(uni(pr[2]));
+  const uint64_t *planes_g = reinterpret_cast<const uint64_t *>(pr + prep_planes_off(sq.ncl));
+  if (NBLK == 0) {
+#pragma unroll 1
+    for (uint32_t i = lane; i < P / 64 * 4; i += 64) planes_lds[i] = planes_g[i];
   }
   wave_sync();
-  const float nrm = __fsqrt_rn(red[1]);
-  const float k1 = red[0] * (-0.5f);
-  // 4-bit scalar code of q' (1 sign bit + 3 magnitude bits), its bit planes, and u = code - 7.5
-  for (uint32_t b = 0; b < P / 64; b++) {
-    const float v = y[b * 64 + lane];
-    const float oa = fabsf(__fdiv_rn(v, nrm));
-    int c = (int)(sq.t_const * (double)oa + 1e-5);
-    c = c >= 8 ? 7 : c;
-    if (v < 0.f) c = (~c) & 7;
-    c += v > 0.f ? 8 : 0;
-    u[b * 64 + lane] = (float)c + (-7.5f);
+  // short codes: the query's bit planes are wave-uniform -> keep them in SGPRs (no LDS reads in the estimator)
+  uint64_t upl[NBLK > 0 ? NBLK * 4 : 1];
+  if (NBLK > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned long long m = __ballot((c >> j) & 1);
-      if (lane == 0) planes[b * 4 + j] = __brevll(m);   // dimension i -> bit 63 - i%64
+    for (int i = 0; i < NBLK * 4; i++) {
+      const uint64_t v = planes_g[i];
+      upl[i] = (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
     }
   }
-  wave_sync();
-  if (lane == 0) {
-    float s = 0.f;
-    for (uint32_t i = 0; i < P; i++) s += y[i] * u[i];
-    red[2] = s;
-  } else if (lane == 1) {
-    float s = 0.f;
-    for (uint32_t i = 0; i < P; i++) s += u[i] * u[i];
-    red[3] = s;
-  }
-  wave_sync();
-  const float nq = __fsqrt_rn(red[3]);
-  const float cos_sim = __fdiv_rn(red[2], nrm * nq);
-  const float delta = __fdiv_rn(nrm, nq) * cos_sim;
-  const float vl = delta * (-7.5f);
+  const uint64_t *planes = NBLK > 0 ? upl : planes_lds;
 
-  uint32_t n_hops = 0, n_est = 1, n_ins = 0, n_rev = 0;
+  uint32_t n_hops = 0, n_est = 1, n_ins = 0, n_rev = 0, n_tr = 0;
   // entry point and greedy descent on estimated distances (:1850-1901)
-  uint32_t cur = ix.enterpoint;
+  uint32_t cur = ix.enterpoint, cur_b = sq.ep_base;   // cur_b = up_base[cur], carried along with cur
   float curd = unif(est_one<NBLK>(sq, planes, gadd, delta, vl, k1, cur));
   for (int lvl = ix.maxlevel; lvl > ix.threshold_level; lvl--) {
     bool changed = true;
     while (changed) {
       changed = false;
+      if (sq.uptile) {
+        // fused upper-level tile of (cur, lvl): the neighbours' records inline, each followed by the neighbour's
+        // own up_base -- one dependent HBM access per descent step instead of up_base -> up_ptr -> ids -> records
+        if (cur_b == kNoneQ) continue;
+        const uint32_t urw = sq.rec_words + 4;
+        const uint32_t *row = sq.uptile + (size_t)(cur_b + lvl - 1) * ((size_t)sq.up_stride * urw);
+        for (uint32_t base = 0; base < sq.up_stride; base += 64) {
+          const uint32_t slot = base + lane;
+          const uint32_t *r = row + (size_t)(slot < sq.up_stride ? slot : 0) * urw;
+          const uint4 h = *reinterpret_cast<const uint4 *>(r);
+          const uint32_t nb_b = r[sq.rec_words];
+          const bool act = slot < sq.up_stride && h.w != kNoneQ;
+          const unsigned long long am = __ballot(act);
+          if (!am) break;
+          const float mine = act ? est_rec<NBLK>(sq, planes, gadd, delta, vl, k1, r, h) : FLT_MAX;
+          n_est += __popcll(am);
+          const float d = wave_min_f32(mine);
+          const unsigned long long eq = __ballot(act && mine == d);
+          if (eq && d < curd) {
+            const int l = __ffsll((long long)eq) - 1;
+            curd = d;
+            cur = __builtin_amdgcn_readlane(h.w, l);
+            cur_b = __builtin_amdgcn_readlane(nb_b, l);
+            changed = true;
+          }
+        }
+        continue;
+      }
       const uint32_t b = uni(ix.up_base[cur]);
       if (b == kNoneQ) continue;
       const uint32_t s = uni(ix.up_ptr[b + lvl - 1]), e = uni(ix.up_ptr[b + lvl]);
@@ -300,12 +464,16 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   float pkey[S];
   uint32_t pval[S];
 #pragma unroll
-  for (int s = 0; s < S; s++) { pkey[s] = 0.f; pval[s] = 0u; }
-  uint32_t psize = 0;
-  pool_insert<S>(pkey, pval, psize, a.pool_cap, curd, cur, lane);
+  for (int s = 0; s < S; s++) { pkey[s] = INFINITY; pval[s] = 0xFFFFFFFFu; }
+  PoolState<S> ps{0u, a.pool_cap, kNoRank, INFINITY};
+  pool_insert<S>(pkey, pval, ps, curd, cur, lane);
   uint32_t heap_n = 0, n_pend = 0, n_set = 0;
   int rc = ST_DONE;
 
+  float hkey = 0.f;      // register heap (k < 64): element j in lane j
+  uint32_t hid = 0u;
+  float heap_root = 0.f;
+  bool heap_dup = false;
   auto flush = [&]() {  // exact distances of the pending expansions, then the k-bounded heap, in expansion order
     wave_sync();
     const int sub = lane & 3, grp = lane >> 2;
@@ -315,13 +483,28 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const uint32_t steps = ix.dim >> 4;
-#pragma unroll 4
+#pragma unroll 1
     for (uint32_t s2 = 0; s2 < steps; s2++) step4<METRIC>(acc, qq[s2 * 4], row[s2 * 4]);
     bool owner;
     const float r = lane4_reduce<METRIC>(acc, sub, owner);
     if (act && owner) pd[grp] = r;
     wave_sync();
-    if (lane == 0) {
+    if (a.k < 64) {
+      const RegHeap rh{hkey, hid, lane};
+      uint32_t hn = heap_n;
+      for (uint32_t j = 0; j < n_pend; j++) {
+        const float dj = unif(pd[j]);
+        // Full heap, no two equal keys in it, new key strictly above the root: push_heap lifts the new element to the
+        // root along its leaf-to-root path and pop_heap's sift-down retraces exactly that path (every path element is
+        // strictly larger than its sibling), leaving the array as it was -- skip the emulation.
+        if (hn == a.k && !heap_dup && dj > heap_root) continue;
+        heap_dup = heap_dup || __ballot((uint32_t)lane < hn && hkey == dj) != 0ull;
+        rh[hn++] = Pair{dj, uni(pend[j])};
+        push_heap(rh, (long)hn, LessD());
+        if (hn > a.k) { pop_heap(rh, (long)hn, LessD()); hn--; }
+        heap_root = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hkey), 0));
+      }
+    } else if (lane == 0) {
       uint32_t hn = heap_n;
       for (uint32_t j = 0; j < n_pend; j++) {
         heap[hn++] = Pair{pd[j], pend[j]};
@@ -334,41 +517,64 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     wave_sync();
   };
 
-  uint32_t node;
-  while (pool_pop<S>(pval, psize, node, lane)) {
-    node &= ~kChecked;
-    if (set_has(tab, mask, node)) { n_rev++; continue; }            // :700-702
+  while (ps.cur != kNoRank) {
+    const uint32_t node = pool_pop<S>(pval, ps, lane);
+    const bool seen = set_has(tab, mask, node);
+    if (a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
+      a.trace[(size_t)qi * a.trace_cap + n_tr] = node | (seen ? kChecked : 0u);
+      a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = ps.size;
+    }
+    n_tr += 2;
+    if (seen) { n_rev++; continue; }                                 // :700-702
     if ((n_set + 1) * 4 > a.hash_slots * 3) { rc = ST_OVERFLOW; break; }
     wave_sync();
     if (lane == 0) set_add(tab, mask, node);                         // :704
     n_set++;
     wave_sync();
-    uint32_t beg, end;
-    if (ix.tile0) { beg = 0; end = ix.tile_stride; }
-    else { beg = uni(ix.row_ptr0[node]); end = uni(ix.row_ptr0[node + 1]); }
-    const uint32_t *adj = ix.tile0 ? ix.tile0 + (size_t)node * ix.tile_stride : ix.cols;
     bool any = false;
-    for (uint32_t base = beg; base < end; base += 64) {
-      const uint32_t c = base + lane < end ? adj[base + lane] : kNoneQ;
-      const bool act = c != kNoneQ;
-      const unsigned long long am = __ballot(act);
-      if (!am) break;
-      any = true;
-      const float d = act ? est_one<NBLK>(sq, planes, gadd, delta, vl, k1, c) : FLT_MAX;
-      n_est += __popcll(am);
-      const bool full = psize == a.pool_cap;
-      const float last = full ? pool_key_at<S>(pkey, a.pool_cap - 1) : FLT_MAX;
+    // the scan of one tile of <= 64 neighbours: estimates d (lanes with act), then the buffer updates in adjacency order
+    auto scan = [&](bool act, uint32_t c, float d) {
+      n_est += __popcll(__ballot(act));
       // is_full() can only turn true as the scan proceeds (the last key never grows once the buffer is full), so
       // the pre-test with the state at the start of the tile rejects nothing the sequential scan would accept
-      unsigned long long pendm = __ballot(act && !(full && d > last) && !set_has(tab, mask, c));
+      unsigned long long pendm = __ballot(act && !(d > ps.last) && !set_has(tab, mask, c));
       while (pendm) {
         const int l = __ffsll((long long)pendm) - 1;
         pendm &= pendm - 1;
         const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
         const uint32_t cj = __builtin_amdgcn_readlane(c, l);
-        if (psize == a.pool_cap && dj > pool_key_at<S>(pkey, a.pool_cap - 1)) continue;   // :741
-        pool_insert<S>(pkey, pval, psize, a.pool_cap, dj, cj, lane);                       // :745
+        if (dj > ps.last) continue;                       // is_full(), :741
+        pool_insert<S>(pkey, pval, ps, dj, cj, lane);      // :745
         n_ins++;
+        if (a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
+          a.trace[(size_t)qi * a.trace_cap + n_tr] = cj | 0x40000000u;
+          a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = __float_as_uint(dj);
+        }
+        n_tr += 2;
+      }
+    };
+    if (sq.ftile) {
+      // fused level-0 tile: slot j of node's row IS neighbour j's record, its header's 4th word the neighbour id
+      // (0xFFFFFFFF = empty slot) -- one dependent HBM access per expansion instead of ids-then-records
+      const uint32_t *row = sq.ftile + (size_t)node * ((size_t)ix.tile_stride * sq.rec_words);
+      for (uint32_t base = 0; base < ix.tile_stride; base += 64) {
+        const uint32_t slot = base + lane;
+        const uint32_t *r = row + (size_t)(slot < ix.tile_stride ? slot : 0) * sq.rec_words;
+        const uint4 h = *reinterpret_cast<const uint4 *>(r);
+        const bool act = slot < ix.tile_stride && h.w != kNoneQ;
+        if (!__ballot(act)) break;
+        any = true;
+        const float d = act ? est_rec<NBLK>(sq, planes, gadd, delta, vl, k1, r, h) : FLT_MAX;
+        scan(act, h.w, d);
+      }
+    } else {
+      const uint32_t beg = uni(ix.row_ptr0[node]), end = uni(ix.row_ptr0[node + 1]);
+      for (uint32_t base = beg; base < end; base += 64) {
+        const bool act = base + lane < end;
+        const uint32_t c = act ? ix.cols[base + lane] : kNoneQ;
+        any = true;
+        const float d = act ? est_one<NBLK>(sq, planes, gadd, delta, vl, k1, c) : FLT_MAX;
+        scan(act, c, d);
       }
     }
     if (!any) continue;   // neighbors == nullptr / size == 0: not reranked either (:708-715)
@@ -381,8 +587,10 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     if (n_pend) flush();
     for (uint32_t j = lane; j < a.k; j += 64) {
       const bool have = j < heap_n;
-      a.out_labels[(size_t)qi * a.k + j] = have ? ix.labels[heap[j].id] : ~0ull;
-      a.out_dists[(size_t)qi * a.k + j] = have ? heap[j].d : INFINITY;
+      const uint32_t hid_j = a.k < 64 ? hid : (have ? heap[j].id : 0u);
+      const float hd_j = a.k < 64 ? hkey : (have ? heap[j].d : 0.f);
+      a.out_labels[(size_t)qi * a.k + j] = have ? ix.labels[hid_j] : ~0ull;
+      a.out_dists[(size_t)qi * a.k + j] = have ? hd_j : INFINITY;
     }
     if (lane == 0) {
       a.out_counts[qi] = heap_n;

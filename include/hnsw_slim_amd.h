@@ -140,6 +140,16 @@ hs_status hs_slimq_search_batch(hs_index *ix, const float *queries, size_t nq, s
 hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, size_t k, uint64_t *d_out_labels,
                                     float *d_out_dists, uint32_t *d_out_counts, uint32_t *d_stats, void *stream);
 
+/* Parity/debug entry: the query preparation as the kernel computed it; out is nq x (padded + 3 + num_cluster +
+ * padded/8) floats: rotated query, {delta, vl, k1xsumq}, g_add per cluster, the 4 bit planes per 64-dim block as raw
+ * u32 pairs (rotator.hpp:370-423, query.hpp:112-156, hnswalg_slimq.h:1822-1848). */
+hs_status hs_slimq_prepare_debug(hs_index *ix, const float *queries, size_t nq, float *out);
+/* Parity/debug entry: the SearchBuffer events of every query in order, two words each (out_trace nq x trace_cap,
+ * 0xFFFFFFFF padding): a pop = {node id (bit 31 set when the node had been expanded before, hnswalg_slimq.h:696-704),
+ * buffer size}, an insert = {candidate id | 1<<30, bits of its estimated distance} (:745). */
+hs_status hs_slimq_trace(hs_index *ix, const float *queries, size_t nq, size_t k, uint32_t *out_trace, size_t trace_cap,
+                         uint32_t *stats);
+
 /* ---- harness (CPU, not accelerated): produce index files in the reference's formats ------------ */
 /* HierarchicalNSW ctor + addPoint loop + saveIndex: hnswalg.h:85-159, 1248-1376, 748-779.
  * labels = row index; threads==1 reproduces the reference's serial build byte for byte. */

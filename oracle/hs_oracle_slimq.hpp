@@ -186,7 +186,7 @@ struct Pool {
 // searchKnn(q, k, result) (hnswalg_slimq.h:1810-1924).  Output = the k-bounded max-heap ARRAY of (exact distance,
 // internal id) in libstdc++ heap order (:1921-1923 reads top_candidates[i] for i < k); `found` = its size.
 inline size_t slimq_search(const SlimQIndex &ix, const float *q, size_t k, std::vector<std::pair<float, uint32_t>> &heap,
-                           SlimQCounters *ctr = nullptr) {
+                           SlimQCounters *ctr = nullptr, std::vector<uint32_t> *trace = nullptr) {
   heap.clear();
   if (ix.count == 0) return 0;
   std::vector<float> rq(ix.padded);
@@ -215,6 +215,7 @@ inline size_t slimq_search(const SlimQIndex &ix, const float *q, size_t k, std::
   pool.insert(cur, curd);
   while (pool.has_next()) {
     uint32_t node = pool.pop();
+    if (trace) { trace->push_back(node | (visited[node] ? 1u << 31 : 0u)); trace->push_back((uint32_t)pool.size); }
     if (visited[node]) { if (ctr) ctr->n_revisit++; continue; }
     visited[node] = 1;
     auto [ids, n] = ix.slice(node, 0);
@@ -227,6 +228,7 @@ inline size_t slimq_search(const SlimQIndex &ix, const float *q, size_t k, std::
       if (pool.is_full(d) || visited[c]) continue;
       pool.insert(c, d);
       if (ctr) ctr->n_insert++;
+      if (trace) { uint32_t b; memcpy(&b, &d, 4); trace->push_back(c | (1u << 30)); trace->push_back(b); }
     }
     const float od = dist(ix.metric == METRIC_IP ? METRIC_IP : METRIC_L2, q, ix.raw + (size_t)node * ix.dim, ix.dim);
     heap.emplace_back(od, node);

@@ -179,4 +179,26 @@ int hso_slimq_search(void *p, const float *q, size_t nq, size_t k, uint64_t *out
   }
   return 0;
 }
+// the SearchBuffer pops of one query in order (bit 31 = revisit); returns the number of pops
+size_t hso_slimq_trace(void *p, const float *q, size_t k, uint32_t *out, size_t cap) {
+  auto *ix = (SlimQIndex *)p;
+  std::vector<std::pair<float, uint32_t>> heap;
+  std::vector<uint32_t> tr;
+  slimq_search(*ix, q, k, heap, nullptr, &tr);
+  for (size_t i = 0; i < tr.size() && i < cap; i++) out[i] = tr[i];
+  return tr.size();
+}
+// rotation + preparation of queries against a loaded index: rq n x padded, q3 n x 3, planes, g_add n x ncl
+void hso_slimq_prepare(void *p, const float *q, size_t n, float *rq, float *q3, uint64_t *planes, float *g_add) {
+  auto *ix = (SlimQIndex *)p;
+  SlimQIndex::Query Q;
+  for (size_t i = 0; i < n; i++) {
+    float *r = rq + i * ix->padded;
+    ix->rotate(q + i * ix->dim, r);
+    ix->prepare(r, Q);
+    q3[i * 3] = Q.delta; q3[i * 3 + 1] = Q.vl; q3[i * 3 + 2] = Q.k1xsumq;
+    std::copy(Q.planes.begin(), Q.planes.end(), planes + i * Q.planes.size());
+    for (size_t c = 0; c < ix->ncl; c++) g_add[i * ix->ncl + c] = ix->metric == METRIC_IP ? -Q.q2c[c] : Q.q2c[c] * Q.q2c[c];
+  }
+}
 }

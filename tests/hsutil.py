@@ -116,6 +116,9 @@ class Oracle:
         L.hso_slimq_set.argtypes = [vp, sz, dbl, vp]
         L.hso_slimq_info.argtypes = [vp, vp]
         L.hso_slimq_search.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, ci]
+        L.hso_slimq_prepare.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        L.hso_slimq_trace.restype = sz
+        L.hso_slimq_trace.argtypes = [vp, vp, sz, vp, sz]
         L.hso_rq_rotate.argtypes = [sz, vp, vp, sz, vp]
         L.hso_rq_prepare.argtypes = [sz, ci, dbl, vp, sz, vp, sz, vp, vp, vp]
         L.hso_rq_est.argtypes = [sz, ci, vp, vp, sz, vp, vp, vp, sz, vp]
@@ -200,6 +203,20 @@ class OracleSlimQ:
         self._raw = np.ascontiguousarray(raw, np.float32)
         assert self._raw.shape == (self.count, self.dim)
         self.o.L.hso_slimq_set(self.h, ef, float(t_const), self._raw.ctypes.data)
+
+    def prepare(self, q):
+        q = np.ascontiguousarray(q, np.float32)
+        n = q.shape[0]
+        rq = np.empty((n, self.padded), np.float32); q3 = np.empty((n, 3), np.float32)
+        pl = np.empty((n, self.padded // 64 * 4), np.uint64); ga = np.empty((n, self.ncl), np.float32)
+        self.o.L.hso_slimq_prepare(self.h, q.ctypes.data, n, rq.ctypes.data, q3.ctypes.data, pl.ctypes.data, ga.ctypes.data)
+        return dict(rq=rq, q3=q3, g_add=ga, planes=pl)
+
+    def trace(self, q1, k, cap=4096):
+        q1 = np.ascontiguousarray(q1, np.float32).reshape(-1)
+        out = np.full(cap, 0xFFFFFFFF, np.uint32)
+        n = self.o.L.hso_slimq_trace(self.h, q1.ctypes.data, k, out.ctypes.data, cap)
+        return out[:min(n, cap)]
 
     def search(self, q, k, threads=1):
         """searchKnn(q, k, result): labels/dists in the reference's heap-array order, count found, counters

@@ -51,6 +51,11 @@ def check(P, O, path, base, q, metric, k, efs, t_const=None):
     for ef in efs:
         ix.set_ef(ef)
         ox.set(ef, ix.slimq_tconst(), base)
+        if ef == efs[0]:
+            gp, op = ix.slimq_prepare_debug(q, ox.padded, ox.ncl), ox.prepare(q)
+            for key in ("rq", "q3", "g_add"):
+                assert np.array_equal(gp[key].view(np.uint32), op[key].view(np.uint32)), f"query preparation differs: {key}"
+            assert np.array_equal(gp["planes"], op["planes"])
         got = ix.slimq_search(q, k, want_stats=True)
         ref = ox.search(q, k, threads=8)
         assert np.array_equal(got["stats"].astype(np.uint64), ref["counters"]), f"traversal differs at ef={ef}"
@@ -103,6 +108,17 @@ def test_slimq_d768_ip(env):
     base, q = x[:2500], x[2500:]
     path = build(P, tmp, "d768", base, 1, 4)
     check(P, O, path, base, q, 1, 10, (50,), t_const=88.0)
+
+
+def test_slimq_csr_fallback_layout(env, monkeypatch):
+    """The layout wide graphs (level-0 degree > 64) fall back to -- CSR adjacency + separate record array, no fused
+    tiles -- forced through the HS_SLIMQ_FUSED=0 knob (the Slim conversion never produces such degrees itself)."""
+    P, O, tmp = env
+    x = sift_like(3000 + 100, 64, seed=31, n_clusters=8)
+    base, q = x[:3000], x[3000:]
+    path = build(P, tmp, "csr", base, 0, 4)
+    monkeypatch.setenv("HS_SLIMQ_FUSED", "0")
+    check(P, O, path, base, q, 0, 10, (40, 150))
 
 
 def test_slimq_threshold_level_and_errors(env):

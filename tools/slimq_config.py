@@ -50,12 +50,22 @@ with tempfile.TemporaryDirectory() as tmp:
     ix = hs.Index(qp, hs.HS_KIND_SLIMQ, d, metric=metric)
     ox = Oracle().load_slimq(qp)
 ix.slimq_set_dataset(base)
+ox.set(64, ix.slimq_tconst(), base)
+gp, op = ix.slimq_prepare_debug(q, ox.padded, ox.ncl), ox.prepare(q)
+for key in ("rq", "q3", "g_add"):
+    neq = (gp[key].view(np.uint32) != op[key].view(np.uint32))
+    print(f"prep {key}: {int(neq.any(axis=1).sum())} of {nq} queries differ, {int(neq.sum())} elements", flush=True)
+    if neq.any():
+        i, j = np.argwhere(neq)[0]; print("   first:", i, j, gp[key][i, j], op[key][i, j], hex(gp[key].view(np.uint32)[i, j]), hex(op[key].view(np.uint32)[i, j]))
+print("prep planes equal:", bool(np.array_equal(gp["planes"], op["planes"])), flush=True)
 print("device bytes", ix.info()["device_bytes"], "t_const", ix.slimq_tconst(), flush=True)
 lab = torch.empty((nq, 10), dtype=torch.int64, device=dev); dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
 cnt = torch.empty((nq,), dtype=torch.int32, device=dev); st = torch.empty((nq, 4), dtype=torch.int32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
+streams = [torch.cuda.Stream() for _ in range(4)]
+outs = [(torch.empty_like(lab), torch.empty_like(dd), torch.empty_like(cnt)) for _ in range(4)]
 rec_bytes = 16 + (d + 63) // 64 * 8
-for ef in (32, 64, 96, 128, 192, 256, 384, 512):
+for ef in [int(e) for e in os.environ.get("EFS", "32,64,96,128,192,256,384,512").split(",")]:
     ix.set_ef(ef); ox.set(ef, ix.slimq_tconst(), base)
     for _ in range(2):
         ix.slimq_search_dev(qt, 10, lab, dd, cnt, st, s); ix.check(s)
@@ -64,9 +74,41 @@ for ef in (32, 64, 96, 128, 192, 256, 384, 512):
     for _ in range(5):
         ix.slimq_search_dev(qt, 10, lab, dd, cnt, None, s)
     e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 5
+    # pipelined over 4 HIP streams (as bench.py does for the fp32 path): hides the last-wave tail of each launch
+    for st_, o_ in zip(streams, outs):
+        ix.slimq_search_dev(qt, 10, o_[0], o_[1], o_[2], None, st_.cuda_stream)
+    torch.cuda.synchronize(); t0 = time.time()
+    for r_ in range(16):
+        st_, o_ = streams[r_ % 4], outs[r_ % 4]
+        ix.slimq_search_dev(qt, 10, o_[0], o_[1], o_[2], None, st_.cuda_stream)
+    torch.cuda.synchronize(); ms4 = (time.time() - t0) * 1e3 / 16
+    for st_ in streams: ix.check(st_.cuda_stream)
     L = lab.cpu().numpy().astype(np.uint64); S = st.cpu().numpy().astype(np.int64)
     t0 = time.time(); want = ox.search(q[:200], 10, threads=32); tcpu = time.time() - t0
     same = bool(np.array_equal(L[:200], want["labels"])) and bool(np.array_equal(S[:200], want["counters"].astype(np.int64)))
+    if not same:
+        bad = [i for i in range(200) if not (np.array_equal(L[i], want["labels"][i]) and np.array_equal(S[i], want["counters"][i].astype(np.int64)))]
+        i = bad[0]
+        print(f"  MISMATCH in {len(bad)} of 200 queries; first {i}: gpu stats {S[i].tolist()} oracle {want['counters'][i].tolist()}")
+        print("   gpu labels", L[i].tolist(), "\n   ora labels", want["labels"][i].tolist())
+        tg, sg = ix.slimq_trace(q[i:i + 1], 10, 16384)
+        tg2, _ = ix.slimq_trace(q[i:i + 1], 10, 16384)
+        to = ox.trace(q[i], 10, 16384); to2 = ox.trace(q[i], 10, 16384)
+        tg = tg[0][:len(to) + 4]
+        print("   gpu runs equal", bool(np.array_equal(tg, tg2[0][:len(tg)])), "oracle runs equal", bool(np.array_equal(to, to2)), "single-query gpu stats", sg[0].tolist())
+        m = min(len(tg), len(to)); dv = np.nonzero(tg[:m] != to[:m])[0]
+        print("   pops oracle", len(to), "first divergence at pop", (int(dv[0]) if len(dv) else None))
+        if len(dv):
+            j = int(dv[0]); print("   gpu", [hex(int(v)) for v in tg[max(0, j - 3):j + 5]], "\n   ora", [hex(int(v)) for v in to[max(0, j - 3):j + 5]])
+            j &= ~1
+            print("   gpu", [hex(int(v)) for v in tg[max(0, j - 6):j + 8]], "\n   ora", [hex(int(v)) for v in to[max(0, j - 6):j + 8]])
+            cand = int(tg[j]) & 0x3FFFFFFF
+            prev = [(k2, hex(int(to[k2 + 1]))) for k2 in range(0, j, 2) if int(to[k2]) == (cand | 0x40000000)]
+            print("   earlier inserts of it (event, d bits) oracle:", prev, " gpu d bits now:", hex(int(tg[j + 1])))
+            pops_before = [int(v) & 0x3FFFFFFF for v in to[:j] if not (int(v) & 0x40000000)]
+            print("   extra candidate", cand, "popped before:", cand in pops_before, "times inserted before:", sum(1 for v in to[:j] if int(v) == (cand | 0x40000000)))
+            import pickle; pickle.dump(dict(tg=tg, to=to, q=q[i]), open(os.path.join(ROOT, "gpurun_out", "slimq_diverge.pkl"), "wb"))
+        print("   gpu dists", dd.cpu().numpy()[i].tolist(), "\n   ora dists", want["dists"][i].tolist(), flush=True)
     by = S[:, 1] * rec_bytes + S[:, 0] * (4 * d + 4 * 32)   # estimates x record + expansions x (raw row + adjacency tile)
-    print(f"ef={ef}: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} hops={S[:,0].mean():.0f} est={S[:,1].mean():.0f} ins={S[:,2].mean():.0f} "
+    print(f"ef={ef}: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} qps_4streams={nq/ms4*1e3:.0f} hops={S[:,0].mean():.0f} est={S[:,1].mean():.0f} ins={S[:,2].mean():.0f} "
           f"revisit={S[:,3].mean():.0f} alg_GB/s={by.sum()/ms/1e6:.0f} oracle_match_first200={same} oracle_32thr_qps={200/tcpu:.0f}", flush=True)
