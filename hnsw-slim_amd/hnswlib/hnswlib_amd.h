@@ -245,4 +245,55 @@ class HierarchicalNSWSlim<float> : public AlgorithmInterface<float>, public deta
   void setExactOrder(bool on) { detail::check(hs_set_exact_order(h_, on ? 1 : 0)); }
 };
 
+// HierarchicalNSWSlimQ (hnswalg_slimq.h): the RaBitQ-quantised variant.  Same call sequence as the reference's
+// strategy (include/strategy/hnsw_slimq_strategy.h:72,142-156): loadIndex, setDataset, setEf, searchKnn(q, K, result).
+template <typename dist_t>
+class HierarchicalNSWSlimQ;
+
+template <>
+class HierarchicalNSWSlimQ<float> : public AlgorithmInterface<float>, public detail::DeviceIndex {
+ public:
+  explicit HierarchicalNSWSlimQ(SpaceInterface<float> *) {}
+  HierarchicalNSWSlimQ(SpaceInterface<float> *s, const std::string &location, bool /*nmslib*/ = false,
+                       size_t max_elements = 0, bool /*allow_replace_deleted*/ = false) {
+    loadIndex(location, s, max_elements);
+  }
+  void loadIndex(const std::string &location, SpaceInterface<float> *s, size_t max_elements_i = 0) {
+    load(location, HS_KIND_SLIMQ, s, max_elements_i);
+  }
+  // setDataset (hnswalg_slimq.h:303-305): the raw rows, indexed by internal id, for the exact re-rank
+  void setDataset(std::vector<std::vector<float>> *data_set) {
+    if (!h_ || !data_set || data_set->empty()) return;
+    const size_t n = data_set->size(), d = (*data_set)[0].size();
+    std::vector<float> flat(n * d);
+    for (size_t i = 0; i < n; i++) std::copy((*data_set)[i].begin(), (*data_set)[i].end(), flat.begin() + i * d);
+    detail::check(hs_slimq_set_dataset(h_, flat.data(), n, d));
+  }
+  void setDataset(const float *rows, size_t n, size_t d) { detail::check(hs_slimq_set_dataset(h_, rows, n, d)); }
+  void setTConst(double t) { detail::check(hs_slimq_set_tconst(h_, t)); }
+  void addPoint(const void *, labeltype, bool = false) override {
+    throw std::runtime_error("HierarchicalNSWSlimQ does not support addPoint");  // hnswalg_slimq.h:298-301
+  }
+  void saveIndex(const std::string &) override {
+    throw std::runtime_error("hnswlib_amd: the device index is read-only; the file it was loaded from is unchanged");
+  }
+  // the priority_queue overloads of the reference print "todo: searchKnn()" and return nothing (:1795-1808)
+  std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *, size_t, BaseFilterFunctor * = nullptr) const override {
+    return {};
+  }
+  // searchKnn(q, k, tableint* result): hnswalg_slimq.h:1810-1924 -- k labels in the reference's heap-array order
+  void searchKnn(const void *query_data, size_t k, tableint *result) const {
+    if (!h_) return;
+    std::vector<uint64_t> lab(k);
+    detail::check(hs_slimq_search_batch(h_, (const float *)query_data, 1, k, lab.data(), nullptr, nullptr, nullptr));
+    for (size_t i = 0; i < k; i++) result[i] = (tableint)lab[i];
+  }
+  // The fast entry: every row of `queries` in one launch; results nq x k.
+  void searchKnnBatch(const float *queries, size_t nq, size_t k, tableint *results) const {
+    std::vector<uint64_t> lab(nq * k);
+    detail::check(hs_slimq_search_batch(h_, queries, nq, k, lab.data(), nullptr, nullptr, nullptr));
+    for (size_t i = 0; i < nq * k; i++) results[i] = (tableint)lab[i];
+  }
+};
+
 }  // namespace hnswlib

@@ -5,6 +5,8 @@
 //   errors                      : CPU-safe checks of the reference's error conventions
 //   slim  <slim.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32>      : per-query searchKnn + batch
 //   hnsw  <hnsw.bin> <dim> <queries.f32> <nq> <k> <ef> <out.bin>      : priority_queue overload
+//   slimq <slimq.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32> <base.f32> <n>   : HierarchicalNSWSlimQ, the
+//         call sequence of include/strategy/hnsw_slimq_strategy.h:72,142-156
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -61,6 +63,22 @@ int main(int argc, char **argv) {
     ix.setExactOrder(true);
     std::vector<hnswlib::tableint> one(k), all(nq * k);
     for (size_t i = 0; i < nq; i++) {  // the reference's serial query loop (hnsw_slim_strategy.h:112-114)
+      ix.searchKnn(Q.data() + i * dim, k, one.data());
+      out.write((char *)one.data(), 4 * k);
+    }
+    ix.searchKnnBatch(Q.data(), nq, k, all.data());
+    out.write((char *)all.data(), 4 * nq * k);
+  } else if (mode == "slimq") {
+    if (argc < 11) return 2;
+    const size_t n = atoll(argv[10]);
+    auto B = read_f32(argv[9], n * dim);
+    std::vector<std::vector<float>> data_set(n);
+    for (size_t i = 0; i < n; i++) data_set[i].assign(B.begin() + i * dim, B.begin() + (i + 1) * dim);
+    hnswlib::HierarchicalNSWSlimQ<float> ix(&space, path);
+    ix.setDataset(&data_set);
+    ix.setEf(ef);
+    std::vector<hnswlib::tableint> one(k), all(nq * k);
+    for (size_t i = 0; i < nq; i++) {  // hnsw_slimq_strategy.h:151-153
       ix.searchKnn(Q.data() + i * dim, k, one.data());
       out.write((char *)one.data(), 4 * k);
     }

@@ -137,3 +137,26 @@ def test_slimq_threshold_level_and_errors(env):
     with pytest.raises(P.HsError) as e:
         fresh.slimq_search(q, 10)   # no dataset yet
     assert e.value.status == P.HS_ERR_INVALID
+
+
+def test_slimq_cpp_facade(env):
+    """A caller written against the reference's HierarchicalNSWSlimQ API (tests/facade_smoke.cpp, the call sequence
+    of hnsw_slimq_strategy.h): per-query searchKnn(q, K, result) loop and searchKnnBatch."""
+    import subprocess
+    from hsutil import ROOT
+    P, O, tmp = env
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "facade_smoke")
+    assert os.path.exists(exe)
+    x = sift_like(2000 + 30, 64, seed=41, n_clusters=8)
+    base, q = np.ascontiguousarray(x[:2000]), np.ascontiguousarray(x[2000:])
+    path = build(P, tmp, "facade", base, 0, 4)
+    qf, bf, out = str(tmp / "fq.f32"), str(tmp / "fb.f32"), str(tmp / "fo.u32")
+    q.tofile(qf)
+    base.tofile(bf)
+    subprocess.check_call([exe, "slimq", path, "64", qf, "30", "10", "50", out, bf, "2000"])
+    got = np.fromfile(out, np.uint32).reshape(2, 30, 10)
+    ox = O.load_slimq(path)
+    ox.set(50, P.rabitq_default_tconst(64), base)
+    want = ox.search(q, 10)
+    assert (want["counts"] == 10).all()
+    assert np.array_equal(got[0], want["labels"].astype(np.uint32)) and np.array_equal(got[1], want["labels"].astype(np.uint32))
