@@ -148,7 +148,7 @@ def main():
 
     # ---- ef sweep: recall + counters at every point; pick the operating point -----------------------
     sweep = {}
-    efs = [args.ef] if args.ef else [32, 48, 64, 72, 80, 96, 128, 192, 256]
+    efs = [args.ef] if args.ef else [32, 48, 64, 68, 72, 80, 96, 128, 192, 256]
     chosen = None
     for ef in efs:
         run(ef, stats=True)

@@ -18,7 +18,7 @@ if which == "sift":
 else:
     n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 768, 1000, 1
     def gen(m, seed):
-        x = sift_like(m, d, seed, n_clusters=2048, rank=32, sigma_sub=40.0, sigma_iso=3.0, integer=False, centre_lo=-60, centre_hi=60)
+        x = sift_like(m, d, seed, n_clusters=4096, rank=12, sigma_sub=40.0, sigma_iso=1.0, integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
 t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
 dev = torch.device("cuda", 0)
