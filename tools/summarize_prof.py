@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn the raw output of tools/prof_cmd.sh (gpurun_out/r01) into the committed summaries under profiles/:
+bench JSON lines, rocprofv3 kernel stats, and the HBM-traffic figure bench.py reports as roofline.traffic."""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r01")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def newest(pattern):
+    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
+def per_launch(path, kernel_sub, counters):
+    tot = {c: 0.0 for c in counters}
+    n = {c: 0 for c in counters}
+    for r in csv.DictReader(open(path)):
+        if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] in tot:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            n[r["Counter_Name"]] += 1
+    return {c: tot[c] / max(n[c], 1) for c in counters}, n
+
+
+for s in ("1stream", "4streams"):
+    shutil.copy(os.path.join(SRC, f"bench_{s}.json"), os.path.join(DST, f"{tag}_bench_1gpu_{s}.json"))
+    ks = newest(f"kt_{s}/**/*kernel_stats.csv")
+    rows = [l for i, l in enumerate(open(ks)) if i == 0 or "hs::" in l]
+    open(os.path.join(DST, f"{tag}_kernel_stats_{s}.csv"), "w").writelines(rows)
+b = json.load(open(os.path.join(SRC, "bench_1stream.json")))
+ef = b["config"]["ef_search"]
+fetch, _ = per_launch(newest("pmc_FETCH_SIZE/**/*counter_collection.csv"), "fast_kernel", ["FETCH_SIZE"])
+write, _ = per_launch(newest("pmc_WRITE_SIZE/**/*counter_collection.csv"), "fast_kernel", ["WRITE_SIZE"])
+tcc, _ = per_launch(newest("pmc_TCC_HIT_sum/**/*counter_collection.csv"), "fast_kernel", ["TCC_HIT_sum", "TCC_MISS_sum"])
+cal, ncal = per_launch(newest("pmc_calib/**/*counter_collection.csv"), "gather", ["FETCH_SIZE"])
+known = 1 << 30
+corr = known / (cal["FETCH_SIZE"] * 1024)
+hbm = fetch["FETCH_SIZE"] * 1024 * corr + write["WRITE_SIZE"] * 1024
+out = {
+    "workload": f"SIFT-1M-like d=128 N=1000000 nq=10000 ef={ef} k=10, 1 stream",
+    "ef": ef,
+    "kernel": "hs::fast_kernel<0,2,8>",
+    "FETCH_SIZE_KiB_per_launch": round(fetch["FETCH_SIZE"], 1),
+    "WRITE_SIZE_KiB_per_launch": round(write["WRITE_SIZE"], 1),
+    "calibration": {
+        "kernel": "tools/gather_calib.hip mode A (same lane mapping as wave_dists), 1 GiB of distinct random 512-B rows, average of the launches",
+        "known_bytes": known, "FETCH_SIZE_KiB": round(cal["FETCH_SIZE"], 1), "fetch_correction": round(corr, 4)},
+    "hbm_bytes_per_launch": int(hbm),
+    "TCC_HIT_sum": int(tcc["TCC_HIT_sum"]), "TCC_MISS_sum": int(tcc["TCC_MISS_sum"]),
+    "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_step"],
+    "note": "FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md HBM); corrected by the factor measured on "
+            "this access pattern; separate --pmc passes for FETCH_SIZE, WRITE_SIZE and TCC_HIT/MISS (tools/prof_cmd.sh)"}
+json.dump(out, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
