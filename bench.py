@@ -278,12 +278,15 @@ def main():
                        "ef_search": chosen, "recall_at_10": round(recall, 4), "sweep": sweep, "index": info,
                        "build_s": round(t_build, 1), "convert_s": round(t_conv, 1), "build_threads": threads,
                        "pipelining": f"steps issued round-robin on {S} HIP streams (up to {S} batches in flight)"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launch_ms_effective": round(step_ms, 4), "launches_in_flight": S,
-                         "single_launch_ms": round(kern_ms, 4), "single_launch_achieved": round(achieved_single, 1),
-                         "single_launch_frac": round(achieved_single / HBM_PEAK_GBS, 4),
-                         "algorithmic_bytes_per_step": alg_bytes_step},
+            # achieved/frac: algorithmic bytes of one launch / the HIP-event duration of that launch alone on the GPU
+            # (what a rocprofv3 kernel-trace average for fast_kernel measures, profiles/r01_kernel_stats_1stream.csv);
+            # pipelined_*: the same bytes / the effective per-step time of the timed region, S launches in flight.
+            "roofline": {"bound": "hbm", "achieved": round(achieved_single, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_single / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "hs::fast_kernel", "launch_ms": round(kern_ms, 4),
+                         "pipelined_achieved": round(achieved, 1), "pipelined_frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "pipelined_ms_per_step": round(step_ms, 4), "launches_in_flight": S,
+                         "algorithmic_bytes_per_launch": alg_bytes_step},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -48,7 +48,7 @@ out = {
         "known_bytes": known, "FETCH_SIZE_KiB": round(cal["FETCH_SIZE"], 1), "fetch_correction": round(corr, 4)},
     "hbm_bytes_per_launch": int(hbm),
     "TCC_HIT_sum": int(tcc["TCC_HIT_sum"]), "TCC_MISS_sum": int(tcc["TCC_MISS_sum"]),
-    "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_step"],
+    "algorithmic_bytes_per_launch": b["roofline"].get("algorithmic_bytes_per_launch", b["roofline"].get("algorithmic_bytes_per_step")),
     "note": "FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md HBM); corrected by the factor measured on "
             "this access pattern; separate --pmc passes for FETCH_SIZE, WRITE_SIZE and TCC_HIT/MISS (tools/prof_cmd.sh)"}
 json.dump(out, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
