@@ -62,7 +62,7 @@ __host__ __device__ inline StrictLds strict_layout(uint32_t dim, uint32_t ef, ui
 }
 // Fast path: no result array in LDS (it lives in registers); heap element i sits at cand slot i+1.  When a
 // tie has to be resolved the reference's result heap is rebuilt in the visited-set area, which is dead by then.
-struct FastLds { uint32_t off_q, off_cand, off_hash, off_nid, off_nd, total; };
+struct FastLds { uint32_t off_q, off_cand, off_hash, off_nid, off_nd, off_stage, total; };
 __host__ __device__ inline FastLds fast_layout(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
   FastLds l;
   l.off_q = 0;
@@ -71,7 +71,8 @@ __host__ __device__ inline FastLds fast_layout(uint32_t dim, uint32_t ef, uint32
   const uint32_t hash_bytes = hash_slots * 4 > (ef + 1) * 8 ? hash_slots * 4 : (ef + 1) * 8;
   l.off_nid = l.off_hash + align_up(hash_bytes, 16);
   l.off_nd = l.off_nid + 64 * 4;
-  l.total = l.off_nd + 64 * 4;
+  l.off_stage = l.off_nd + 64 * 4;              // ef x 8 B: result-set merge staging (batched accept)
+  l.total = l.off_stage + align_up(ef * 8, 16);
   return l;
 }
 size_t strict_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
@@ -734,12 +735,81 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     HS_LAP(c, 3);
     const float my_d = (uint32_t)lane < cnt ? nd[lane] : FLT_MAX;
     const uint32_t my_id = (uint32_t)lane < cnt ? nid[lane] : 0;
-    // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
-    // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
-    unsigned long long todo = __ballot((uint32_t)lane < cnt && (top_size < ef || lb > my_d));
     float best_d = FLT_MAX;
     uint32_t best_id = 0;
     bool have_best = false;
+    if (bare) {
+      // ---- accept decisions (:403-452) for the whole tile at once --------------------------------------------
+      // The reference scans the new neighbours in adjacency order, accepting j iff top_size < ef || lowerBound > d_j
+      // with the result set updated after every acceptance.  Equivalent closed form: with T the result set before
+      // this tile, j is accepted iff  #{t in T : t <= d_j} + #{i < j : d_i <= d_j}  <  ef  (every earlier neighbour
+      // that is not farther is itself accepted whenever j is, and evicted entries only ever lie beyond the ef-th
+      // rank).  Accepted entries then merge into the sorted set in one pass: an old entry moves up by the number of
+      // accepted keys strictly below it, an accepted one lands at #{T <= d} + #{accepted before it in (d, j) order}.
+      // Same set, same lowerBound sequence as far as any decision can see, a third of the vector instructions.
+      const bool cand_ok = (uint32_t)lane < cnt && (top_size < ef || lb > my_d);
+      const unsigned long long pm = __ballot(cand_ok);
+      if (pm) {
+        uint32_t A = 0, B = 0;
+        for (unsigned long long m = pm; m; m &= m - 1) {
+          const int j = __ffsll((long long)m) - 1;
+          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
+          uint32_t a = 0;
+#pragma unroll
+          for (int s = 0; s < S; s++) a += __popcll(__ballot((uint32_t)(lane + 64 * s) < top_size && tk[s] <= dj));
+          if (lane == j) A = a;
+          B += (cand_ok && lane > j && dj <= my_d) ? 1u : 0u;
+        }
+        const bool acc = cand_ok && (A + B < ef);
+        const unsigned long long am = __ballot(acc);
+        const uint32_t n_acc = __popcll(am);
+        uint32_t Bp = 0, shift[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) shift[s] = 0;
+        for (unsigned long long m = am; m; m &= m - 1) {
+          const int j = __ffsll((long long)m) - 1;
+          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
+          Bp += (acc && (dj < my_d || (dj == my_d && j < lane))) ? 1u : 0u;
+#pragma unroll
+          for (int s = 0; s < S; s++) shift[s] += tk[s] > dj ? 1u : 0u;
+        }
+        uint2 *stage = reinterpret_cast<uint2 *>(smem + L.off_stage);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint32_t r = lane + 64 * s, nr = r + shift[s];
+          if (r < top_size && nr < ef) stage[nr] = make_uint2(__float_as_uint(tk[s]), ti[s]);
+        }
+        if (acc && A + Bp < ef) stage[A + Bp] = make_uint2(__float_as_uint(my_d), my_id);
+        wave_sync();
+        top_size = min(top_size + n_acc, ef);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint32_t r = lane + 64 * s;
+          if (r < top_size) {
+            const uint2 e = stage[r];
+            tk[s] = __uint_as_float(e.x);
+            ti[s] = e.y;
+          }
+        }
+        wave_sync();
+        lb = top_key_at<S>(tk, top_size - 1);  // :450-452
+        pending |= am;
+        if (am) {
+          best_d = wave_min_f32(acc ? my_d : FLT_MAX);
+          const int bl = __ffsll((long long)__ballot(acc && my_d == best_d)) - 1;
+          best_id = __builtin_amdgcn_readlane(my_id, bl);
+          have_best = true;
+          if (tlog && acc) {
+            const uint32_t at = n_log + __popcll(am & ((1ull << lane) - 1ull));
+            if (at < a.log_cap) tlog[at] = make_uint2(__float_as_uint(my_d), my_id);
+          }
+          n_log += n_acc;
+        }
+      }
+    } else {
+    // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
+    // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
+    unsigned long long todo = __ballot((uint32_t)lane < cnt && (top_size < ef || lb > my_d));
     while (todo) {
       const int j = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
@@ -756,6 +826,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         if (top_size > 0) lb = top_key_at<S>(tk, top_size - 1);  // :450-452
       }
     }
+    }  // !bare
     // root of candidate_set after the pending pushes
     if (cand_size > 0) {
       const uint2 root = cand.lds[1];
