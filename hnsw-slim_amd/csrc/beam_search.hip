@@ -195,6 +195,15 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
                                             uint32_t cnt, int lane, Hook between = Hook()) {
   const int sub = lane & 3, grp = lane >> 2;
   float out = FLT_MAX;
+  if (D16 == 0 && METRIC == METRIC_L2 && (ix.dim & 15u)) {
+    // dim % 16 != 0: the reference's SIMD4 / residual recipes (dist_recipe.hpp l2_general), one lane per row
+    for (uint32_t base = 0; base < cnt; base += 64) {
+      const uint32_t j = base + lane;
+      if (j < cnt) nd[j] = l2_general(qv, ix.vec + (size_t)nid[j] * ix.dim, ix.dim);
+      if (base == 0) between();
+    }
+    return out;
+  }
   const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
   for (uint32_t base = 0; base < cnt; base += 16) {
     const uint32_t j = base + grp;

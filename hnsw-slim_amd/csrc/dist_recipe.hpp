@@ -57,8 +57,68 @@ inline float ip_row16(const float *q, const float *x, size_t d) {
   float ip = h[0] + h[1];
   return 1.0f - ip;
 }
+// L2Space's dispatch for every dim (space_l2.h:214-234): dim%16==0 -> SIMD16 (above); dim%4==0 -> SIMD4
+// (:166-190: 4 lane accumulators, TmpRes[0..3] summed left to right); dim>16 -> SIMD16 on the first dim/16*16
+// elements + scalar L2Sqr on the rest (:149-160); dim>4 -> SIMD4 + scalar rest (:192-205); else scalar (:6-20).
+// One thread does a whole row: usable per lane on the device (runtime-dim kernels) and by the host builder.
+HS_HD float l2_part16(const float *q, const float *x, uint32_t d16) {
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) acc[j] = 0.f;
+  for (uint32_t s = 0; s < d16; s += 16) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const float t = q[s + j] - x[s + j];
+      const float p = t * t;
+      acc[j] = acc[j] + p;
+    }
+  }
+  float r = acc[0];
+#pragma unroll
+  for (int j = 1; j < 16; j++) r = r + acc[j];
+  return r;
+}
+HS_HD float l2_part4(const float *q, const float *x, uint32_t d4) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (uint32_t s = 0; s < d4; s += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float t = q[s + j] - x[s + j];
+      const float p = t * t;
+      acc[j] = acc[j] + p;
+    }
+  }
+  return ((acc[0] + acc[1]) + acc[2]) + acc[3];
+}
+HS_HD float l2_scalar(const float *q, const float *x, uint32_t d) {
+  float r = 0.f;
+  for (uint32_t i = 0; i < d; i++) {
+    const float t = q[i] - x[i];
+    const float p = t * t;
+    r = r + p;
+  }
+  return r;
+}
+HS_HD float l2_general(const float *q, const float *x, uint32_t d) {
+  if ((d & 15u) == 0) return l2_part16(q, x, d);
+  if ((d & 3u) == 0) return l2_part4(q, x, d);
+  if (d > 16) {
+    const uint32_t d16 = d & ~15u;
+    const float r = l2_part16(q, x, d16);
+    const float t = l2_scalar(q + d16, x + d16, d - d16);
+    return r + t;
+  }
+  if (d > 4) {
+    const uint32_t d4 = d & ~3u;
+    const float r = l2_part4(q, x, d4);
+    const float t = l2_scalar(q + d4, x + d4, d - d4);
+    return r + t;
+  }
+  return l2_scalar(q, x, d);
+}
 inline float host_dist(Metric m, const float *q, const float *x, size_t d) {
-  return m == METRIC_L2 ? l2_row16(q, x, d) : ip_row16(q, x, d);
+  if (m == METRIC_L2) return (d & 15) ? l2_general(q, x, (uint32_t)d) : l2_row16(q, x, d);
+  return ip_row16(q, x, d);   // callers guarantee dim % 16 == 0 for the inner product
 }
 
 }  // namespace hs

@@ -10,7 +10,7 @@ namespace hs {
 
 // Read-only index resident in HBM (one copy per GPU).
 struct DevIndex {
-  const float *vec;         // n x dim fp32, row-major, rows 64-byte aligned (dim % 16 == 0)
+  const float *vec;         // n x dim fp32, row-major, rows 64-byte aligned when dim % 16 == 0
   const uint32_t *row_ptr0; // n+1     : CSR row pointers of the level-0 adjacency
   const uint32_t *cols;     // n_edges : neighbour ids (level 0 first, then upper-level slices)
   const uint32_t *up_base;  // n       : first up_ptr entry of node i, 0xFFFFFFFF when level(i)==0

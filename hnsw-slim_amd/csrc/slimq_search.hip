@@ -477,6 +477,9 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   auto flush = [&]() {  // exact distances of the pending expansions, then the k-bounded heap, in expansion order
     wave_sync();
     const int sub = lane & 3, grp = lane >> 2;
+    if (METRIC == METRIC_L2 && (ix.dim & 15u)) {  // the reference's SIMD4 / residual recipes, one lane per row
+      if ((uint32_t)lane < n_pend) pd[lane] = l2_general(qv, sq.raw + (size_t)pend[lane] * ix.dim, ix.dim);
+    } else {
     const bool act = (uint32_t)grp < n_pend;
     const uint32_t id = pend[act ? grp : 0];
     const float4 *row = reinterpret_cast<const float4 *>(sq.raw + (size_t)id * ix.dim) + sub;
@@ -488,6 +491,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     bool owner;
     const float r = lane4_reduce<METRIC>(acc, sub, owner);
     if (act && owner) pd[grp] = r;
+    }
     wave_sync();
     if (a.k < 64) {
       const RegHeap rh{hkey, hid, lane};

@@ -56,12 +56,10 @@ class SpaceInterface {
 class L2Space : public SpaceInterface<float> {
   size_t data_size_, dim_;
   static float fn(const void *a, const void *b, const void *p) {
-    return hs::l2_row16((const float *)a, (const float *)b, *(const size_t *)p);
+    return hs::host_dist(hs::METRIC_L2, (const float *)a, (const float *)b, *(const size_t *)p);  // every dim
   }
  public:
-  explicit L2Space(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {
-    if (dim % 16) throw std::runtime_error("hnswlib_amd: dim % 16 != 0 is not supported yet");
-  }
+  explicit L2Space(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {}
   size_t get_data_size() override { return data_size_; }
   DISTFUNC<float> get_dist_func() override { return fn; }
   void *get_dist_func_param() override { return &dim_; }
@@ -73,7 +71,7 @@ class InnerProductSpace : public SpaceInterface<float> {
   }
  public:
   explicit InnerProductSpace(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {
-    if (dim % 16) throw std::runtime_error("hnswlib_amd: dim % 16 != 0 is not supported yet");
+    if (dim % 16) throw std::runtime_error("hnswlib_amd: inner product with dim % 16 != 0 is not supported yet");
   }
   size_t get_data_size() override { return data_size_; }
   DISTFUNC<float> get_dist_func() override { return fn; }

@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
       ok += std::string(e.what()) == "HierarchicalNSWSlim does not support addPoint";
     }
     try {
-      hnswlib::L2Space bad(30);
+      hnswlib::InnerProductSpace bad(30);
     } catch (std::runtime_error &) {
       ok++;
     }

@@ -147,6 +147,9 @@ def main():
         deleted_fixture(tmp, "l2_int_d16", "l2", 16, 5, [10, 48])
         filter_fixture(tmp, "l2_cont_d32", "l2", 3, 1, [10, 32, 64])
         filter_fixture(tmp, "l2_int_d16_del", "l2", 4, 0, [10, 48])   # delete marks AND a filter
+        # dims off the SIMD16 path: L2SqrSIMD4Ext (d=20), SIMD16ExtResiduals (d=21), SIMD4ExtResiduals (d=10)
+        for d, seed in ((20, 11), (21, 13), (10, 15)):
+            index_fixture(tmp, f"l2_cont_d{d}", "l2", mixture(600, d, seed), mixture(40, d, seed + 1), 8, 60, [10, 32])
         rabitq_fixture(tmp)
     print("golden fixtures written to", GOLDEN)
 

@@ -33,7 +33,8 @@ def _pq_sorted(d, l, c):
     return out
 
 
-@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48)])
+@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48),
+                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10)])
 def test_vanilla_vs_compiled_reference(hs, oracle, name, metric, dim):
     g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     path = os.path.join(GOLDEN, f"{name}.hnsw.bin")
@@ -175,6 +176,14 @@ def test_k_larger_than_ef_and_k_equals_n(hs, oracle, tmp_path):
     q = mixture(20, 16, 34)
     ix, ox = _slim_case(hs, oracle, tmp_path, base, q, 16, L2, 8, 50, [4], k=20, fast=False)  # ef = max(ef_, k)
     assert ix.info()["n"] == 500
+
+
+@pytest.mark.parametrize("dim", (100, 70))
+def test_slim_dims_off_the_simd16_path(hs, oracle, tmp_path, dim):
+    """dim % 16 != 0: the reference's SIMD4 (d=100) and SIMD16+residual (d=70) L2 recipes, strict and fast kernels."""
+    base = mixture(6000, dim, 61, integer=True)
+    q = mixture(100, dim, 62, integer=True)
+    _slim_case(hs, oracle, tmp_path, base, q, dim, L2, 16, 100, [32, 100])
 
 
 def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):

@@ -100,6 +100,15 @@ def test_slimq_d96_padded_rotator(env):
     check(P, O, path, base, q, 0, 10, (30, 100))
 
 
+def test_slimq_d100_residual_recipes(env):
+    """dim 100 (GloVe-like): padded 128, Kac walk, and the exact re-rank through the reference's SIMD4 L2 recipe."""
+    P, O, tmp = env
+    x = sift_like(3000 + 100, 100, seed=71, n_clusters=16)
+    base, q = x[:3000], x[3000:]
+    path = build(P, tmp, "d100", base, 0, 8)
+    check(P, O, path, base, q, 0, 10, (40, 120))
+
+
 def test_slimq_d768_ip(env):
     P, O, tmp = env
     rng = np.random.default_rng(9)

@@ -26,7 +26,8 @@ def test_distance_recipes_bit_exact(oracle):
     assert checked >= 14
 
 
-@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48)])
+@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48),
+                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10)])
 def test_vanilla_search_matches_reference(oracle, name, metric, dim):
     g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     ix = oracle.load(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "hnsw", metric, dim)
