@@ -145,9 +145,13 @@ __device__ __forceinline__ void vis_commit(Visited &v, uint32_t cnt) {
 // Both tiers are arrays of 4-slot buckets probed with one 16-byte read: an id sits in the first bucket,
 // in probe order from its home bucket, that had a free slot when it arrived (nothing is ever deleted), so
 // a lookup ends at the first bucket that contains the id or still has a free slot.
+// Slots of a bucket fill in order (an insert always takes the first free one), so the free slots are a suffix and
+// -- ids being below 2^31, kEmpty = 0xFFFFFFFF the only value with the sign bit set -- their number is minus the sum
+// of the four arithmetic sign extensions.  A dozen vector instructions instead of a compare/select ladder.
 __device__ __forceinline__ int bucket_scan(const uint4 &w, uint32_t id) {  // -2 found, -1 full, else free slot
-  if (w.x == id || w.y == id || w.z == id || w.w == id) return -2;
-  return w.x == kEmpty ? 0 : w.y == kEmpty ? 1 : w.z == kEmpty ? 2 : w.w == kEmpty ? 3 : -1;
+  const uint32_t hit = min(min(w.x ^ id, w.y ^ id), min(w.z ^ id, w.w ^ id));
+  const int used = 4 + (((int)w.x >> 31) + ((int)w.y >> 31) + ((int)w.z >> 31) + ((int)w.w >> 31));
+  return hit == 0 ? -2 : (used < 4 ? used : -1);
 }
 __device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
   const uint32_t h = id * 2654435761u;
@@ -247,7 +251,7 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
 
 // Shared prologue: stage the query, clear the visited set, entry distance, upper-layer greedy descent
 // (hnswalg_slim.h:2033-2078, hnswalg.h:1385-1415).  Leaves (cur, curdist) = level-0 entry.
-template <int METRIC>
+template <int METRIC, int D16 = 0>
 __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a, uint32_t qi, float *qv, Visited &vis,
                                         uint32_t *hash, uint32_t *nid, float *nd, Counters &c, uint32_t &cur,
                                         float &curdist, int lane) {
@@ -256,7 +260,7 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
   cur = ix.enterpoint;
   if (lane == 0) nid[0] = cur;
   wave_sync();
-  wave_dists<METRIC>(ix, qv, nid, nd, 1, lane);
+  wave_dists<METRIC, D16>(ix, qv, nid, nd, 1, lane);
   wave_sync();
   curdist = unif(nd[0]);
   c.n_dist = 1;
@@ -278,7 +282,7 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
         wave_sync();
         if ((uint32_t)lane < m) nid[lane] = ix.cols[base + lane];
         wave_sync();
-        wave_dists<METRIC>(ix, qv, nid, nd, m, lane);
+        wave_dists<METRIC, D16>(ix, qv, nid, nd, m, lane);
         wave_sync();
         c.n_nbr += m;
         c.n_dist += m;
@@ -656,7 +660,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   uint32_t cur;
   float curdist;
   Visited vis;
-  descend<METRIC>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
+  descend<METRIC, D16>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
   HS_LAP(c, 5);
 
   const bool bare = !ix.has_deleted;
@@ -944,7 +948,7 @@ __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
 template <int METRIC, int S, int D16>
-__global__ void __launch_bounds__(64) fast_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
     if (!((1u << a.status[qi]) & a.select_mask)) continue;
