@@ -31,8 +31,15 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def ground_truth(torch, base_t, q_t, k):
-    """Exact L2 k-NN by brute force on the GPU (fp32; integer-valued data => exact)."""
+def ground_truth(torch, base_t, q_t, k, hs=None):
+    """Exact L2 k-NN by brute force on the GPU.  With the product module: its exhaustive-scan kernel (the reference's
+    BruteforceSearch semantics, exact recipe distances, ties broken by label); otherwise a torch GEMM (fp32;
+    exact on integer-valued data)."""
+    if hs is not None and base_t.shape[1] % 16 == 0 and k <= 64:
+        lab = torch.empty((q_t.shape[0], k), dtype=torch.int64, device=q_t.device)
+        dd = torch.empty((q_t.shape[0], k), dtype=torch.float32, device=q_t.device)
+        hs.brute_force_dev(base_t, q_t, k, lab, dd)
+        return lab.cpu().numpy()
     bn = (base_t * base_t).sum(1)
     out = []
     for s in range(0, q_t.shape[0], 1024):
@@ -132,7 +139,7 @@ def main():
         ix.set_capacity(args.cand_cap, args.hash_slots)
     base_t = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
     q_t = torch.from_numpy(queries).to(dev)
-    gt = ground_truth(torch, base_t, q_t, K)
+    gt = ground_truth(torch, base_t, q_t, K, hs)
     del base_t
     torch.cuda.empty_cache()
 

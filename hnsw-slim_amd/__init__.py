@@ -24,7 +24,7 @@ EXPORTS = [
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
     "hs_build_hnsw", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
-    "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug",
+    "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
 ]
 
 
@@ -88,6 +88,8 @@ def lib():
     L.hs_slimq_search_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.hs_slimq_trace.argtypes = [vp, vp, sz, sz, vp, sz, vp]
     L.hs_slimq_prepare_debug.argtypes = [vp, vp, sz, vp]
+    L.hs_brute_force.argtypes = [vp, sz, sz, ci, vp, vp, sz, sz, ci, vp, vp, vp]
+    L.hs_brute_force_dev.argtypes = [vp, vp, sz, sz, ci, vp, sz, sz, vp, vp, vp, vp]
     L.hs_rabitq_rotate.argtypes = [sz, vp, vp, sz, vp]
     L.hs_rabitq_quantize_data.argtypes = [sz, ci, vp, sz, vp, vp, vp]
     L.hs_rabitq_prepare_query.argtypes = [sz, ctypes.c_double, vp, sz, vp, vp]
@@ -117,6 +119,26 @@ def convert_slim(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=
     """HierarchicalNSWSlim::convertFromHNSW + saveIndex, on the CPU (harness)."""
     _check(lib().hs_convert_slim(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
                                  top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
+
+
+def brute_force(base, queries, k, metric=HS_METRIC_L2, labels=None, device=0):
+    """hnswlib::BruteforceSearch::searchKnn for a batch: (labels, dists) nq x k, ascending by (dist, label)."""
+    b = np.ascontiguousarray(base, np.float32)
+    q = np.ascontiguousarray(queries, np.float32)
+    lab = None if labels is None else np.ascontiguousarray(labels, np.uint64)
+    ol = np.empty((q.shape[0], k), np.uint64)
+    od = np.empty((q.shape[0], k), np.float32)
+    oc = np.empty(q.shape[0], np.uint32)
+    _check(lib().hs_brute_force(b.ctypes.data, b.shape[0], b.shape[1], metric, None if lab is None else lab.ctypes.data, q.ctypes.data,
+                                q.shape[0], k, device, ol.ctypes.data, od.ctypes.data, oc.ctypes.data))
+    return ol, od, oc
+
+
+def brute_force_dev(d_base, d_queries, k, d_labels_out, d_dists_out, metric=HS_METRIC_L2, d_counts=None, stream=0):
+    """Device tensors (torch): base n x d, queries nq x d, outputs int64 / float32 nq x k."""
+    _check(lib().hs_brute_force_dev(d_base.data_ptr(), None, d_base.shape[0], d_base.shape[1], metric, d_queries.data_ptr(),
+                                    d_queries.shape[0], k, d_labels_out.data_ptr(), d_dists_out.data_ptr(),
+                                    d_counts.data_ptr() if d_counts is not None else None, stream))
 
 
 def convert_slimq(slim_path, metric, dim, centroids, out_path, cluster_ids=None, flip_seed=1, threads=8):

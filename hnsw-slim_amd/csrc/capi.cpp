@@ -20,6 +20,7 @@
 #include "rabitq_est.hpp"
 #include "rabitq_host.hpp"
 #include "slimq_engine.hpp"
+#include "bf_engine.hpp"
 
 using namespace hs;
 
@@ -724,6 +725,51 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
   } catch (std::exception &e) {
     return from_exception(e);
   }
+  return HS_OK;
+}
+
+// ---- exhaustive k-NN: hnswlib::BruteforceSearch::searchKnn (bruteforce.h:106-135) for a batch ----------------------
+hs_status hs_brute_force_dev(const float *d_base, const uint64_t *d_labels, size_t n, size_t dim, int metric,
+                             const float *d_queries, size_t nq, size_t k, uint64_t *d_out_labels, float *d_out_dists,
+                             uint32_t *d_out_counts, void *stream_) {
+  if (!d_base || !d_queries || !d_out_labels || !d_out_dists) return fail(HS_ERR_INVALID, "null argument");
+  if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
+  if (dim == 0 || dim % 16 != 0) return fail(HS_ERR_UNSUPPORTED, "brute force supports dim % 16 == 0 only");
+  if (k == 0 || k > 64) return fail(HS_ERR_UNSUPPORTED, "brute force supports 1 <= k <= 64");
+  if (n > 0xFFFFFFF0u || nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "too many rows / queries");
+  if (nq == 0) return HS_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  uint32_t gx = 0, rpb = 0;
+  const size_t bytes = bf_partial_bytes((uint32_t)n, (uint32_t)nq, (uint32_t)k, &gx, &rpb);
+  void *partial = nullptr;
+  HIP_TRY(hipMalloc(&partial, std::max<size_t>(bytes, 16)));
+  hipError_t e = launch_brute_force(d_base, d_labels, (uint32_t)n, (uint32_t)dim, metric, d_queries, (uint32_t)nq, (uint32_t)k, partial, gx,
+                                    rpb, d_out_labels, d_out_dists, d_out_counts, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return fail(HS_ERR_DEVICE, std::string("brute force: ") + hipGetErrorString(e));
+  return HS_OK;
+}
+
+hs_status hs_brute_force(const float *base, size_t n, size_t dim, int metric, const uint64_t *labels, const float *queries,
+                         size_t nq, size_t k, int device, uint64_t *out_labels, float *out_dists, uint32_t *out_counts) {
+  if (!base || !queries || !out_labels || !out_dists) return fail(HS_ERR_INVALID, "null argument");
+  if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
+  if (nq == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevBuf<float> db, dq, dd;
+  DevBuf<uint64_t> dl, dol;
+  DevBuf<uint32_t> dc;
+  HIP_TRY(db.alloc(std::max<size_t>(n * dim, 1))); HIP_TRY(dq.alloc(nq * dim)); HIP_TRY(dd.alloc(nq * k)); HIP_TRY(dol.alloc(nq * k));
+  HIP_TRY(dc.alloc(nq));
+  if (labels) { HIP_TRY(dl.alloc(std::max<size_t>(n, 1))); HIP_TRY(hipMemcpy(dl.p, labels, n * 8, hipMemcpyHostToDevice)); }
+  HIP_TRY(hipMemcpy(db.p, base, n * dim * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dq.p, queries, nq * dim * 4, hipMemcpyHostToDevice));
+  hs_status s = hs_brute_force_dev(db.p, labels ? dl.p : nullptr, n, dim, metric, dq.p, nq, k, dol.p, dd.p, dc.p, nullptr);
+  if (s != HS_OK) return s;
+  HIP_TRY(hipMemcpy(out_labels, dol.p, nq * k * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_dists, dd.p, nq * k * 4, hipMemcpyDeviceToHost));
+  if (out_counts) HIP_TRY(hipMemcpy(out_counts, dc.p, nq * 4, hipMemcpyDeviceToHost));
   return HS_OK;
 }
 

@@ -243,6 +243,51 @@ class HierarchicalNSWSlim<float> : public AlgorithmInterface<float>, public deta
   void setExactOrder(bool on) { detail::check(hs_set_exact_order(h_, on ? 1 : 0)); }
 };
 
+// BruteforceSearch (bruteforce.h): exhaustive scan.  addPoint keeps the rows on the host; searchKnn / searchKnnBatch
+// run the exhaustive-scan kernel over them (hs_brute_force: same distances, same (dist, label) tie order).
+template <typename dist_t>
+class BruteforceSearch;
+
+template <>
+class BruteforceSearch<float> : public AlgorithmInterface<float> {
+  std::vector<float> rows_;
+  std::vector<uint64_t> labels_;
+  size_t dim_ = 0, max_ = 0;
+  int metric_ = HS_METRIC_L2;
+ public:
+  BruteforceSearch(SpaceInterface<float> *s, size_t maxElements) : dim_(detail::dim_of(s)), max_(maxElements), metric_(detail::metric_of(s)) {
+    rows_.reserve(maxElements * dim_);
+    labels_.reserve(maxElements);
+  }
+  void addPoint(const void *datapoint, labeltype label, bool = false) override {
+    for (size_t i = 0; i < labels_.size(); i++)
+      if (labels_[i] == label) {  // bruteforce.h:66-70: an existing label is overwritten in place
+        std::copy((const float *)datapoint, (const float *)datapoint + dim_, rows_.begin() + i * dim_);
+        return;
+      }
+    if (labels_.size() >= max_) throw std::runtime_error("The number of elements exceeds the specified limit\n");  // :72-74
+    rows_.insert(rows_.end(), (const float *)datapoint, (const float *)datapoint + dim_);
+    labels_.push_back(label);
+  }
+  void saveIndex(const std::string &) override { throw std::runtime_error("hnswlib_amd: BruteforceSearch::saveIndex is not provided"); }
+  std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k, BaseFilterFunctor *f = nullptr) const override {
+    if (f) throw std::runtime_error("hnswlib_amd: BruteforceSearch with a filter is not provided");
+    std::priority_queue<std::pair<float, labeltype>> r;
+    if (labels_.empty()) return r;
+    std::vector<uint64_t> lab(k);
+    std::vector<float> d(k);
+    uint32_t cnt = 0;
+    detail::check(hs_brute_force(rows_.data(), labels_.size(), dim_, metric_, labels_.data(), (const float *)query_data, 1, k, 0, lab.data(),
+                                 d.data(), &cnt));
+    for (uint32_t i = 0; i < cnt; i++) r.emplace(d[i], (labeltype)lab[i]);
+    return r;
+  }
+  // every row of `queries` in one launch; out_* are nq x k, ascending by (dist, label)
+  void searchKnnBatch(const float *queries, size_t nq, size_t k, uint64_t *out_labels, float *out_dists, uint32_t *out_counts = nullptr) const {
+    detail::check(hs_brute_force(rows_.data(), labels_.size(), dim_, metric_, labels_.data(), queries, nq, k, 0, out_labels, out_dists, out_counts));
+  }
+};
+
 // HierarchicalNSWSlimQ (hnswalg_slimq.h): the RaBitQ-quantised variant.  Same call sequence as the reference's
 // strategy (include/strategy/hnsw_slimq_strategy.h:72,142-156): loadIndex, setDataset, setEf, searchKnn(q, K, result).
 template <typename dist_t>

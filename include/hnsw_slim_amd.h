@@ -150,6 +150,17 @@ hs_status hs_slimq_prepare_debug(hs_index *ix, const float *queries, size_t nq, 
 hs_status hs_slimq_trace(hs_index *ix, const float *queries, size_t nq, size_t k, uint32_t *out_trace, size_t trace_cap,
                          uint32_t *stats);
 
+/* ---- exhaustive k-NN (ground truth): hnswlib::BruteforceSearch::searchKnn, bruteforce.h:106-135, for a batch ------
+ * Result per query: the k lexicographically smallest (dist, label) pairs -- what the reference's priority_queue of
+ * pairs ends up holding whatever the scan order -- sorted ascending; distances by the same fp32 recipes as the
+ * graph search.  labels NULL = row index.  dim % 16 == 0, k <= 64.  out_counts[q] = min(k, n). */
+hs_status hs_brute_force(const float *base, size_t n, size_t dim, int metric, const uint64_t *labels, const float *queries,
+                         size_t nq, size_t k, int device, uint64_t *out_labels, float *out_dists, uint32_t *out_counts);
+/* device pointers; synchronises `stream` before returning */
+hs_status hs_brute_force_dev(const float *d_base, const uint64_t *d_labels, size_t n, size_t dim, int metric,
+                             const float *d_queries, size_t nq, size_t k, uint64_t *d_out_labels, float *d_out_dists,
+                             uint32_t *d_out_counts, void *stream);
+
 /* ---- harness (CPU, not accelerated): produce index files in the reference's formats ------------ */
 /* HierarchicalNSW ctor + addPoint loop + saveIndex: hnswalg.h:85-159, 1248-1376, 748-779.
  * labels = row index; threads==1 reproduces the reference's serial build byte for byte. */

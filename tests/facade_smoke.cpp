@@ -5,6 +5,7 @@
 //   errors                      : CPU-safe checks of the reference's error conventions
 //   slim  <slim.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32>      : per-query searchKnn + batch
 //   hnsw  <hnsw.bin> <dim> <queries.f32> <nq> <k> <ef> <out.bin>      : priority_queue overload
+//   bf    <base.f32> <dim> <queries.f32> <nq> <k> <n> <out.bin>         : BruteforceSearch addPoint + searchKnn
 //   slimq <slimq.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32> <base.f32> <n>   : HierarchicalNSWSlimQ, the
 //         call sequence of include/strategy/hnsw_slimq_strategy.h:72,142-156
 #include <cstdio>
@@ -57,6 +58,17 @@ int main(int argc, char **argv) {
   auto Q = read_f32(argv[4], nq * dim);
   hnswlib::L2Space space(dim);
   std::ofstream out(argv[8], std::ios::binary);
+  if (mode == "bf") {
+    const size_t n = ef;  // 7th argument is the row count in this mode
+    auto B = read_f32(path, n * dim);
+    hnswlib::BruteforceSearch<float> bf(&space, n);
+    for (size_t i = 0; i < n; i++) bf.addPoint(B.data() + i * dim, 1000 + 3 * i);
+    for (size_t i = 0; i < nq; i++) {
+      auto r = bf.searchKnn(Q.data() + i * dim, k);   // farthest on top, as the reference's priority_queue
+      while (!r.empty()) { uint64_t l = r.top().second; float d = r.top().first; out.write((char *)&d, 4); out.write((char *)&l, 8); r.pop(); }
+    }
+    return 0;
+  }
   if (mode == "slim") {
     hnswlib::HierarchicalNSWSlim<float> ix(&space, path);
     ix.setEf(ef);

@@ -1,0 +1,83 @@
+"""Exhaustive k-NN kernel (hs_brute_force) against the oracle's restatement of BruteforceSearch::searchKnn:
+the k lexicographically smallest (dist, label) pairs, distances bit-identical to the reference recipes."""
+import numpy as np
+import pytest
+
+from hsutil import Oracle, load_product, mixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    return load_product(), Oracle()
+
+
+def _expect(O, metric, base, q, k, labels=None):
+    """(labels, dists) by exact recipe distances, lexicographic (dist, label)."""
+    n = base.shape[0]
+    lab = np.arange(n, dtype=np.uint64) if labels is None else labels
+    outl, outd = [], []
+    for i in range(q.shape[0]):
+        d = O.dist(metric, np.repeat(q[i:i + 1], n, axis=0), base)
+        order = np.lexsort((lab, d))[:k]
+        outl.append(lab[order]); outd.append(d[order])
+    return np.array(outl), np.array(outd)
+
+
+@pytest.mark.parametrize("n,d,nq,k,metric,integer", [(5000, 128, 37, 10, 0, True), (777, 32, 9, 1, 0, False), (3000, 96, 20, 64, 0, True),
+                                                     (2500, 48, 16, 10, 1, False), (40, 16, 5, 10, 0, True), (9, 16, 3, 10, 0, False)])
+def test_brute_force_matches_reference_semantics(env, n, d, nq, k, metric, integer):
+    P, O = env
+    if integer:   # tiny value range: many exactly equal distances -> the label tie-break decides
+        base = mixture(n, d, 5, lo=0, hi=4, sigma=1.0, integer=True)
+        q = mixture(nq, d, 6, lo=0, hi=4, sigma=1.0, integer=True)
+    else:
+        base, q = mixture(n, d, 7), mixture(nq, d, 8)
+    if metric == 1:
+        base /= np.linalg.norm(base, axis=1, keepdims=True); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    gl, gd, gc = P.brute_force(base, q, k, metric)
+    el, ed = _expect(O, metric, base, q, min(k, n))
+    kk = min(k, n)
+    assert np.all(gc == kk)
+    assert np.array_equal(gl[:, :kk], el)
+    assert np.array_equal(gd[:, :kk].view(np.uint32), ed.view(np.uint32))
+    if kk < k:
+        assert np.all(gl[:, kk:] == np.iinfo(np.uint64).max) and np.all(np.isinf(gd[:, kk:]))
+
+
+def test_brute_force_custom_labels_break_ties(env):
+    P, O = env
+    base = mixture(2000, 16, 9, lo=0, hi=3, sigma=0.8, integer=True)
+    q = mixture(12, 16, 10, lo=0, hi=3, sigma=0.8, integer=True)
+    labels = np.random.default_rng(3).permutation(2000).astype(np.uint64) * 7 + 5
+    gl, gd, _ = P.brute_force(base, q, 10, 0, labels=labels)
+    el, ed = _expect(O, 0, base, q, 10, labels)
+    assert np.array_equal(gl, el) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+
+
+def test_brute_force_errors(env):
+    P, _ = env
+    base, q = mixture(100, 20, 1), mixture(3, 20, 2)
+    with pytest.raises(P.HsError) as e:
+        P.brute_force(base, q, 5)
+    assert e.value.status == P.HS_ERR_UNSUPPORTED
+    with pytest.raises(P.HsError):
+        P.brute_force(mixture(100, 16, 1), mixture(3, 16, 2), 65)
+
+
+def test_bruteforce_cpp_facade(env, tmp_path):
+    """hnswlib::BruteforceSearch<float> through the facade: addPoint with custom labels, searchKnn pop order."""
+    import os, subprocess
+    from hsutil import ROOT
+    P, O = env
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "facade_smoke")
+    base = mixture(600, 32, 21, lo=0, hi=5, sigma=1.0, integer=True)
+    q = mixture(7, 32, 22, lo=0, hi=5, sigma=1.0, integer=True)
+    bf, qf, out = (str(tmp_path / f) for f in ("b.f32", "q.f32", "o.bin"))
+    base.tofile(bf); q.tofile(qf)
+    subprocess.check_call([exe, "bf", bf, "32", qf, "7", "10", "600", out])
+    rec = np.fromfile(out, np.dtype([("d", "<f4"), ("l", "<u8")])).reshape(7, 10)
+    labels = (1000 + 3 * np.arange(600)).astype(np.uint64)
+    el, ed = _expect(O, 0, base, q, 10, labels)
+    assert np.array_equal(rec["l"][:, ::-1], el) and np.array_equal(rec["d"][:, ::-1].copy().view(np.uint32), ed.view(np.uint32))
