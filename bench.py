@@ -247,6 +247,16 @@ def main():
         elapsed = float(t.item())
     qps = world * NQ * args.steps / elapsed
 
+    # PCIe-inclusive rate of the host-pointer entry (hs_search_batch: H2D of the queries, search, D2H of the labels);
+    # reported for DESIGN.md, never `value`
+    host_api_qps = None
+    if rank == 0 and world == 1:
+        ix.search_ids(queries, K)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ix.search_ids(queries, K)
+        host_api_qps = round(5 * NQ / (time.perf_counter() - t0), 1)
+
     # ---- CPU baseline: the oracle (port) on this box's host cores, rank 0, N=1 only ------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -284,7 +294,8 @@ def main():
                                    f"HNSW-Slim M=16 efC=200 (Slim defaults), k={K}, ef_search={chosen}",
                        "ef_search": chosen, "recall_at_10": round(recall, 4), "sweep": sweep, "index": info,
                        "build_s": round(t_build, 1), "convert_s": round(t_conv, 1), "build_threads": threads,
-                       "pipelining": f"steps issued round-robin on {S} HIP streams (up to {S} batches in flight)"},
+                       "pipelining": f"steps issued round-robin on {S} HIP streams (up to {S} batches in flight)",
+                       "host_pointer_api_qps_pcie_inclusive": host_api_qps},
             # achieved/frac: algorithmic bytes of one launch / the HIP-event duration of that launch alone on the GPU
             # (what a rocprofv3 kernel-trace average for fast_kernel measures, profiles/r01_kernel_stats_1stream.csv);
             # pipelined_*: the same bytes / the effective per-step time of the timed region, S launches in flight.
