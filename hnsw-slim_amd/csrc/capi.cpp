@@ -109,7 +109,6 @@ struct hs_index {
   DevBuf<uint8_t> q_flips;
   DevSlimQ sq{};
   bool has_dataset = false;
-  float *prep_ptr = nullptr;       // debug: rotated queries of the next launch (unused by the ABI entries)
   uint32_t *trace_ptr = nullptr;   // hs_slimq_trace only
   uint32_t trace_cap = 0;
 };
@@ -565,7 +564,7 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   a.trace = ix->trace_ptr; a.trace_cap = ix->trace_cap;
   const uint32_t pw = slimq_prep_words(ix->sq.ncl, ix->sq.padded);
   HIP_TRY(w->prep.ensure(nq * (size_t)pw));
-  HIP_TRY(launch_slimq_prep(ix->sq, (uint32_t)ix->info.dim, ix->info.metric, d_queries, (uint32_t)nq, w->prep.p, ix->prep_ptr, stream));
+  HIP_TRY(launch_slimq_prep(ix->sq, (uint32_t)ix->info.dim, ix->info.metric, d_queries, (uint32_t)nq, w->prep.p, nullptr, stream));
   a.prep = w->prep.p;
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p;
   HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
