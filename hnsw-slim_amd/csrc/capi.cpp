@@ -738,6 +738,8 @@ hs_status hs_brute_force_dev(const float *d_base, const uint64_t *d_labels, size
   if (n > 0xFFFFFFF0u || nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "too many rows / queries");
   if (nq == 0) return HS_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  hipPointerAttribute_t attr;   // run (and allocate the workspace) on the device that holds the rows
+  if (hipPointerGetAttributes(&attr, d_base) == hipSuccess) HIP_TRY(hipSetDevice(attr.device));
   uint32_t gx = 0, rpb = 0;
   const size_t bytes = bf_partial_bytes((uint32_t)n, (uint32_t)nq, (uint32_t)k, &gx, &rpb);
   void *partial = nullptr;
