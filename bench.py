@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cand-cap", type=int, default=0)
     ap.add_argument("--hash-slots", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the timed steps are issued on round-robin (batches in flight); 1 = strictly serial")
     args = ap.parse_args()
 

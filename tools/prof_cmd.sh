@@ -5,10 +5,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r01
 mkdir -p $O
-python bench.py --index-dir /tmp/idx --steps 20 --warmup 4 > $O/bench_4streams.json 2> $O/bench_4streams.log
-EF=$(python -c "import json;print(json.load(open('$O/bench_4streams.json'))['config']['ef_search'])")
+python bench.py --index-dir /tmp/idx --steps 20 --warmup 4 > $O/bench_pipelined.json 2> $O/bench_pipelined.log
+EF=$(python -c "import json;print(json.load(open('$O/bench_pipelined.json'))['config']['ef_search'])")
 python bench.py --index-dir /tmp/idx --ef $EF --streams 1 --steps 20 --warmup 4 --no-cpu-baseline > $O/bench_1stream.json 2> $O/bench_1stream.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_4streams -- python bench.py --index-dir /tmp/idx --ef $EF --steps 20 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_pipelined -- python bench.py --index-dir /tmp/idx --ef $EF --steps 20 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_1stream -- python bench.py --index-dir /tmp/idx --ef $EF --streams 1 --steps 20 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   D=$O/pmc_$(echo $C | cut -d' ' -f1)

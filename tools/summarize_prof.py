@@ -23,7 +23,7 @@ def per_launch(path, kernel_sub, counters):
     return {c: tot[c] / max(n[c], 1) for c in counters}, n
 
 
-for s in ("1stream", "4streams"):
+for s in ("1stream", "pipelined"):
     shutil.copy(os.path.join(SRC, f"bench_{s}.json"), os.path.join(DST, f"{tag}_bench_1gpu_{s}.json"))
     ks = newest(f"kt_{s}/**/*kernel_stats.csv")
     rows = [l for i, l in enumerate(open(ks)) if i == 0 or "hs::" in l]
