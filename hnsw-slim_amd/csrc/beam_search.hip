@@ -269,11 +269,38 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
     if (lane == 0) vis_insert(vis, cur);
     vis.n1++;
   }
+  uint32_t cur_b = ix.ep_base;   // up_base[cur], carried along with cur on the tiled path
   for (int lvl = ix.maxlevel; lvl > ix.threshold_level; lvl--) {
     bool changed = true;
     while (changed) {
       changed = false;
       c.n_hops++;
+      if (ix.uptile) {
+        // upper-level tile of (cur, lvl): {neighbour id, the neighbour's own up_base} pairs at a fixed stride -- the
+        // step is tile -> rows (two dependent HBM accesses) instead of up_base -> up_ptr -> ids -> rows (four)
+        if (cur_b == kNone) continue;
+        uint2 pr = make_uint2(kNone, kNone);
+        if ((uint32_t)lane < ix.up_stride) pr = ix.uptile[(size_t)(cur_b + lvl - 1) * ix.up_stride + lane];
+        const uint32_t m = __popcll(__ballot(pr.x != kNone));   // ids are a prefix of the tile
+        if (m == 0) continue;
+        wave_sync();
+        if ((uint32_t)lane < m) nid[lane] = pr.x;
+        wave_sync();
+        wave_dists<METRIC, D16>(ix, qv, nid, nd, m, lane);
+        wave_sync();
+        c.n_nbr += m;
+        c.n_dist += m;
+        const float mine = (uint32_t)lane < m ? nd[lane] : FLT_MAX;
+        const float d = wave_min_f32(mine);
+        const uint32_t l = (uint32_t)__ffsll((long long)__ballot((uint32_t)lane < m && mine == d)) - 1;
+        if (l < m && d < curdist) {  // hnswalg_slim.h:2071-2075
+          curdist = d;
+          cur = __builtin_amdgcn_readlane(pr.x, l);
+          cur_b = __builtin_amdgcn_readlane(pr.y, l);
+          changed = true;
+        }
+        continue;
+      }
       const uint32_t b = uni(ix.up_base[cur]);
       if (b == kNone) continue;
       const uint32_t s = uni(ix.up_ptr[b + lvl - 1]), e = uni(ix.up_ptr[b + lvl]);

@@ -76,7 +76,7 @@ struct hs_index {
   bool exact_order = false;               // always use the strict kernel (reference output order)
   DevIndex dev{};
   DevBuf<float> vec;
-  DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr, tile0;
+  DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr, tile0, uptile;
   DevBuf<uint64_t> labels;
   DevBuf<uint8_t> deleted;
   // per-stream scratch (grow-only): calls on different HIP streams may be in flight together
@@ -188,6 +188,34 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
       std::copy(p.cols.begin() + p.row_ptr0[i], p.cols.begin() + p.row_ptr0[i + 1], tile.begin() + i * stride);
     HIP_TRY(ix->tile0.upload(tile));
   }
+  // upper-level tiles for the greedy descent (see engine.hpp)
+  uint32_t up_stride = 0;
+  {
+    size_t max_up = 0;
+    for (size_t t = 0; t + 1 < p.up_ptr.size(); t++)
+      if (p.up_ptr[t + 1] > p.up_ptr[t]) max_up = std::max<size_t>(max_up, p.up_ptr[t + 1] - p.up_ptr[t]);
+    if (!p.up_ptr.empty() && max_up <= 64) {
+      up_stride = std::max<uint32_t>(16, (uint32_t)((max_up + 15) / 16 * 16));
+      std::vector<uint32_t> ut(p.up_ptr.size() * (size_t)up_stride * 2, 0xFFFFFFFFu);
+      // a node with L upper levels owns L+1 consecutive up_ptr entries (L list starts + one terminator), in id order
+      std::vector<uint32_t> owners;
+      for (size_t i = 0; i < p.n; i++)
+        if (p.up_base[i] != PackedIndex::NONE) owners.push_back((uint32_t)i);
+      for (size_t o = 0; o < owners.size(); o++) {
+        const uint32_t b0 = p.up_base[owners[o]];
+        const uint32_t end = o + 1 < owners.size() ? p.up_base[owners[o + 1]] : (uint32_t)p.up_ptr.size();
+        for (uint32_t t = b0; t + 1 < end; t++) {
+          const uint32_t s0 = p.up_ptr[t], e0 = p.up_ptr[t + 1];
+          for (uint32_t j = 0; j < e0 - s0; j++) {
+            const uint32_t nb = p.cols[s0 + j];
+            ut[((size_t)t * up_stride + j) * 2] = nb;
+            ut[((size_t)t * up_stride + j) * 2 + 1] = p.up_base[nb];
+          }
+        }
+      }
+      HIP_TRY(ix->uptile.upload(ut));
+    }
+  }
   HIP_TRY(ix->labels.upload(p.labels));
   HIP_TRY(ix->deleted.upload(p.deleted));
   ix->host_labels = p.labels;
@@ -196,6 +224,8 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   d.vec = ix->vec.p; d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p;
   d.up_ptr = ix->up_ptr.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
   d.tile0 = stride ? ix->tile0.p : nullptr; d.tile_stride = stride;
+  d.uptile = up_stride ? reinterpret_cast<const uint2 *>(ix->uptile.p) : nullptr; d.up_stride = up_stride;
+  d.ep_base = p.n ? p.up_base[p.enterpoint] : 0xFFFFFFFFu;
   d.n = (uint32_t)p.n; d.dim = (uint32_t)p.dim; d.maxlevel = p.maxlevel; d.threshold_level = p.threshold_level;
   d.enterpoint = p.enterpoint; d.has_deleted = p.has_deleted; d.kind = p.kind; d.metric = p.metric;
   hs_info &i = ix->info;

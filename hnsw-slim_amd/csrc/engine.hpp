@@ -17,9 +17,11 @@ struct DevIndex {
   const uint32_t *up_ptr;   //         : level-l slice of i = cols[up_ptr[b+l-1] .. up_ptr[b+l])
   const uint32_t *tile0;    // n x tile_stride: level-0 ids of node i padded with 0xFFFFFFFF to one
                             //         aligned tile (stride 16/32/48/64 ids), or null when max degree > 64
+  const uint2 *uptile;      // (#upper slots) x up_stride {neighbour id, up_base[neighbour]}: level l of node i sits at slot
+                            //         up_base[i] + l - 1, padded with 0xFFFFFFFF; null when an upper list exceeds 64 ids
   const uint64_t *labels;   // n
   const uint8_t *deleted;   // n       : delete mark as the reference reads it
-  uint32_t n, dim, tile_stride;
+  uint32_t n, dim, tile_stride, up_stride, ep_base;   // ep_base = up_base[enterpoint]
   int32_t maxlevel, threshold_level;
   uint32_t enterpoint;
   int32_t has_deleted, kind, metric;
