@@ -835,8 +835,9 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         lb = top_key_at<S>(tk, top_size - 1);  // :450-452
         pending |= am;
         if (am) {
-          best_d = wave_min_f32(acc ? my_d : FLT_MAX);
-          const int bl = __ffsll((long long)__ballot(acc && my_d == best_d)) - 1;
+          // the earliest accepted entry with the smallest distance is the one no accepted entry precedes in (d, j) order
+          const int bl = __ffsll((long long)__ballot(acc && Bp == 0)) - 1;
+          best_d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), bl));
           best_id = __builtin_amdgcn_readlane(my_id, bl);
           have_best = true;
           if (tlog && acc) {
