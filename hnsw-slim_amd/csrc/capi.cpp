@@ -572,7 +572,7 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   if (ix->info.kind != HS_KIND_SLIMQ) return fail(HS_ERR_INVALID, "not a SlimQ index");
   if (!ix->has_dataset) return fail(HS_ERR_INVALID, "hs_slimq_set_dataset() first (setDataset, hnswalg_slimq.h:303)");
   if (k == 0 || k > 1024) return fail(HS_ERR_INVALID, "k must be in 1..1024");
-  if (!slimq_supported((uint32_t)ix->ef)) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports 1 <= ef <= 512");
+  if (!slimq_supported((uint32_t)ix->ef)) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports 1 <= ef <= 1024");
   if (nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "nq too large");
   if (nq == 0) return HS_OK;
   hipStream_t stream = (hipStream_t)stream_;

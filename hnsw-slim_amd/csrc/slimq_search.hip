@@ -55,7 +55,7 @@ __host__ __device__ inline SlimQLds slimq_layout(uint32_t dim, uint32_t padded, 
 size_t slimq_lds_bytes(uint32_t dim, uint32_t padded, uint32_t ncl, uint32_t k, uint32_t hash_slots) {
   return slimq_layout(dim, padded, ncl, k, hash_slots).total;
 }
-bool slimq_supported(uint32_t pool_cap) { return pool_cap >= 1 && pool_cap <= 512; }
+bool slimq_supported(uint32_t pool_cap) { return pool_cap >= 1 && pool_cap <= 1024; }
 
 // ---- expanded-node set: open addressing in LDS, inserts by one lane, lookups by all ---------------------------
 __device__ __forceinline__ uint32_t hash_of(uint32_t id, uint32_t mask) { return (id * 2654435761u) >> 7 & mask; }
@@ -631,7 +631,8 @@ static hipError_t launch_ms(const DevIndex &ix, const DevSlimQ &sq, const SlimQA
   if (S <= 1) return launch_k(slimq_kernel<METRIC, 1, NBLK>, ix, sq, a, lds, stream);
   if (S <= 2) return launch_k(slimq_kernel<METRIC, 2, NBLK>, ix, sq, a, lds, stream);
   if (S <= 4) return launch_k(slimq_kernel<METRIC, 4, NBLK>, ix, sq, a, lds, stream);
-  return launch_k(slimq_kernel<METRIC, 8, NBLK>, ix, sq, a, lds, stream);
+  if (S <= 8) return launch_k(slimq_kernel<METRIC, 8, NBLK>, ix, sq, a, lds, stream);
+  return launch_k(slimq_kernel<METRIC, 16, NBLK>, ix, sq, a, lds, stream);
 }
 hipError_t launch_slimq(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, hipStream_t stream) {
   const size_t lds = slimq_lds_bytes(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);

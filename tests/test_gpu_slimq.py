@@ -136,7 +136,8 @@ def test_slimq_threshold_level_and_errors(env):
     base, q = x[:5000], x[5000:]
     path = build(P, tmp, "thr", base, 0, 16, threshold_level=1)
     ix, _ = check(P, O, path, base, q, 0, 10, (60,))
-    ix.set_ef(600)
+    check(P, O, path, base, q[:20], 0, 10, (700, 1024))   # 16 register slots per lane
+    ix.set_ef(1100)
     with pytest.raises(P.HsError) as e:
         ix.slimq_search(q, 10)
     assert e.value.status == P.HS_ERR_UNSUPPORTED
