@@ -22,7 +22,7 @@ HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORT
 EXPORTS = [
     "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
-    "hs_build_hnsw", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
+    "hs_build_hnsw", "hs_build_hnsw_labeled", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
 ]

@@ -722,10 +722,16 @@ hs_status hs_search_batch_raw(hs_index *ix, const float *queries, size_t nq, siz
 
 hs_status hs_build_hnsw(const float *base, size_t n, size_t dim, int metric, size_t M, size_t ef_construction,
                         const char *branching_factor, size_t seed, int threads, const char *out_path) {
+  return hs_build_hnsw_labeled(base, nullptr, n, dim, metric, M, ef_construction, branching_factor, seed, threads, out_path);
+}
+
+hs_status hs_build_hnsw_labeled(const float *base, const uint64_t *labels, size_t n, size_t dim, int metric, size_t M,
+                                size_t ef_construction, const char *branching_factor, size_t seed, int threads,
+                                const char *out_path) {
   if (!base || !out_path || !branching_factor || n == 0) return fail(HS_ERR_INVALID, "bad argument");
   try {
     VanillaGraph g;
-    g.build(base, n, dim, (Metric)metric, M, ef_construction, branching_factor, seed, threads);
+    g.build(base, n, dim, (Metric)metric, M, ef_construction, branching_factor, seed, threads, labels);
     g.save(out_path);
   } catch (std::bad_alloc &) {
     return fail(HS_ERR_NOMEM, "Not enough memory");

@@ -278,7 +278,7 @@ struct VanillaGraph {
   // ids == labels (the reference's parallel build does not, hnswalg.h:1279-1281) but the graph then
   // depends on thread timing, exactly as upstream hnswlib.
   void build(const float *base, size_t n, size_t d, Metric m, size_t M_, size_t efC_, const std::string &bf,
-             size_t seed, int threads) {
+             size_t seed, int threads, const uint64_t *labels = nullptr) {
     init(n, d, m, M_, efC_, bf);
     std::default_random_engine gen;
     gen.seed(seed);
@@ -291,7 +291,7 @@ struct VanillaGraph {
     if (threads < 1) threads = 1;
     Visited v0;
     size_t serial_head = threads > 1 ? std::min<size_t>(n, 1) : n;
-    for (size_t i = 0; i < serial_head; i++) { count = i + 1; add_point(base + i * d, i, i, lv[i], v0); }
+    for (size_t i = 0; i < serial_head; i++) { count = i + 1; add_point(base + i * d, i, labels ? labels[i] : i, lv[i], v0); }
     if (serial_head < n) {
       std::atomic<size_t> next(serial_head);
       std::atomic<bool> failed(false);
@@ -306,7 +306,7 @@ struct VanillaGraph {
             size_t i = next.fetch_add(1);
             if (i >= n || failed) break;
             try {
-              add_point(base + i * d, i, i, lv[i], vl);
+              add_point(base + i * d, i, labels ? labels[i] : i, lv[i], vl);
             } catch (std::exception &e) {
               std::lock_guard<std::mutex> g(err_mu);
               err = e.what();

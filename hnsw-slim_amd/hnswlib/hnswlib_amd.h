@@ -19,11 +19,14 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <fstream>
 #include <queue>
 #include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../../include/hnsw_slim_amd.h"
 #include "../csrc/dist_recipe.hpp"
@@ -169,28 +172,83 @@ class HierarchicalNSW;
 
 template <>
 class HierarchicalNSW<float> : public AlgorithmInterface<float>, public detail::DeviceIndex {
+  // build-then-search callers (include/strategy/hnsw_strategy.h:24-40: ctor, addPoint loop, saveIndex, setEf, searchKnn):
+  // points are collected on the host, the graph is built by the CPU harness (hs_build_hnsw_labeled: the reference's
+  // addPoint loop, serial => the same bytes) the first time it is needed, written to `saveIndex`'s path (or a temporary
+  // file) and loaded onto the device.
+  SpaceInterface<float> *space_ = nullptr;
+  size_t max_elements_ = 0, M_ = 16, efc_ = 200, seed_ = 100;
+  std::string branching_ = "16";
+  std::vector<float> rows_;
+  std::vector<uint64_t> row_labels_;
+  bool dirty_ = false;
+  int build_threads_ = 1;
+  std::string tmp_path_;   // index file of a graph that was built here and never saved by the caller
+  void materialize(const std::string &location) {
+    if (row_labels_.empty()) throw std::runtime_error("hnswlib_amd: nothing to build (no addPoint calls)");
+    detail::check(hs_build_hnsw_labeled(rows_.data(), row_labels_.data(), row_labels_.size(), detail::dim_of(space_), detail::metric_of(space_),
+                                        M_, efc_, branching_.c_str(), seed_, build_threads_, location.c_str()));
+    const size_t ef_keep = ef_;
+    load(location, HS_KIND_HNSW, space_, max_elements_);
+    setEf(ef_keep);
+    dirty_ = false;
+  }
+  void ensure_built() const {
+    if (!dirty_) return;
+    char tmpl[] = "/tmp/hnswlib_amd_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) throw std::runtime_error("Cannot open file");
+    close(fd);
+    auto *self = const_cast<HierarchicalNSW *>(this);
+    if (!self->tmp_path_.empty()) unlink(self->tmp_path_.c_str());
+    self->tmp_path_ = tmpl;
+    self->materialize(tmpl);
+  }
+
  public:
-  explicit HierarchicalNSW(SpaceInterface<float> *) {}
+  ~HierarchicalNSW() { if (!tmp_path_.empty()) unlink(tmp_path_.c_str()); }
+  void build() const { ensure_built(); }   // force the deferred build (convertFromHNSW calls it)
+  explicit HierarchicalNSW(SpaceInterface<float> *s) : space_(s) {}
   HierarchicalNSW(SpaceInterface<float> *s, const std::string &location, bool /*nmslib*/ = false, size_t max_elements = 0,
-                  bool /*allow_replace_deleted*/ = false) {
+                  bool /*allow_replace_deleted*/ = false) : space_(s) {
     loadIndex(location, s, max_elements);
   }
+  // hnswalg.h:85-159
+  HierarchicalNSW(SpaceInterface<float> *s, size_t max_elements, size_t M = 16, size_t ef_construction = 200,
+                  std::string branching_factor = "16", size_t random_seed = 100, bool /*allow_replace_deleted*/ = false)
+      : space_(s), max_elements_(max_elements), M_(M), efc_(ef_construction), seed_(random_seed), branching_(branching_factor) {
+    rows_.reserve(max_elements * detail::dim_of(s));
+    row_labels_.reserve(max_elements);
+  }
+  void setBuildThreads(int t) { build_threads_ = t < 1 ? 1 : t; }   // 1 = the reference's serial addPoint loop, byte for byte
   void loadIndex(const std::string &location, SpaceInterface<float> *s, size_t max_elements_i = 0) {
+    space_ = s;
+    rows_.clear(); row_labels_.clear(); dirty_ = false;
     load(location, HS_KIND_HNSW, s, max_elements_i);
   }
-  void addPoint(const void *, labeltype, bool = false) override {
-    throw std::runtime_error("hnswlib_amd: HierarchicalNSW::addPoint is not on the GPU search path (build with hs_build_hnsw)");
+  void addPoint(const void *datapoint, labeltype label, bool = false) override {
+    if (!space_ || max_elements_ == 0)
+      throw std::runtime_error("hnswlib_amd: addPoint needs the (space, max_elements, M, ef_construction, ..) constructor");
+    if (row_labels_.size() >= max_elements_)
+      throw std::runtime_error("The number of elements exceeds the specified limit");  // hnswalg.h:1289-1291
+    const size_t d = detail::dim_of(space_);
+    rows_.insert(rows_.end(), (const float *)datapoint, (const float *)datapoint + d);
+    row_labels_.push_back(label);
+    dirty_ = true;
   }
-  void saveIndex(const std::string &) override {
-    throw std::runtime_error("hnswlib_amd: the device index is read-only; the file it was loaded from is unchanged");
+  void saveIndex(const std::string &location) override {
+    if (row_labels_.empty()) throw std::runtime_error("hnswlib_amd: the device index is read-only; the file it was loaded from is unchanged");
+    materialize(location);
   }
   std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k,
                                                              BaseFilterFunctor *isIdAllowed = nullptr) const override {
+    ensure_built();
     return search_pq(query_data, k, isIdAllowed);
   }
   // Batched searchKnn: nq x dim queries; out_labels / out_dists nq x k (unused slots: UINT64_MAX / +inf).
   void searchKnnBatch(const float *queries, size_t nq, size_t k, uint64_t *out_labels, float *out_dists,
                       uint32_t *out_counts) const {
+    ensure_built();
     detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_PQ, nullptr, out_labels, out_dists, out_counts, nullptr));
   }
 };
@@ -200,30 +258,66 @@ class HierarchicalNSWSlim;
 
 template <>
 class HierarchicalNSWSlim<float> : public AlgorithmInterface<float>, public detail::DeviceIndex {
+  SpaceInterface<float> *space_ = nullptr;
+  int thr_ = 0;
+  float p0_ = 0.02f, p_ = 0.02f;
+  size_t M0h_ = 32, m0l_ = 8, Mh_ = 16, ml_ = 4;
+  std::string tmp_path_;
+
  public:
-  explicit HierarchicalNSWSlim(SpaceInterface<float> *) {}
+  explicit HierarchicalNSWSlim(SpaceInterface<float> *s) : space_(s) {}
   HierarchicalNSWSlim(SpaceInterface<float> *s, const std::string &location, bool /*nmslib*/ = false,
-                      size_t max_elements = 0, bool /*allow_replace_deleted*/ = false) {
+                      size_t max_elements = 0, bool /*allow_replace_deleted*/ = false) : space_(s) {
     loadIndex(location, s, max_elements);
   }
+  // hnswalg_slim.h:89-143: the pruning parameters live in the object, convertFromHNSW(hnsw) uses them
+  HierarchicalNSWSlim(SpaceInterface<float> *s, size_t /*max_elements*/, size_t /*M*/ = 16, size_t /*ef_construction*/ = 200,
+                      size_t threshold_level = 0, float top_degree_percent0 = 0.02f, float top_degree_percent = 0.02f,
+                      size_t top_degree_M0 = 32, size_t low_degree_m0 = 8, size_t top_degree_M = 16, size_t low_degree_m = 4,
+                      size_t /*random_seed*/ = 100, bool /*allow_replace_deleted*/ = false)
+      : space_(s), thr_((int)threshold_level), p0_(top_degree_percent0), p_(top_degree_percent), M0h_(top_degree_M0),
+        m0l_(low_degree_m0), Mh_(top_degree_M), ml_(low_degree_m) {}
+  ~HierarchicalNSWSlim() { if (!tmp_path_.empty()) unlink(tmp_path_.c_str()); }
   void loadIndex(const std::string &location, SpaceInterface<float> *s, size_t max_elements_i = 0) {
+    space_ = s;
     load(location, HS_KIND_SLIM, s, max_elements_i);
   }
-  // convertFromHNSW (hnswalg_slim.h:867-1108) + saveIndex to `slim_location`, then load it on the device.
+  // convertFromHNSW(hnsw) (hnswalg_slim.h:867-1108) with the object's parameters; the Slim file goes to a temporary
+  // path until saveIndex names one
+  void convertFromHNSW(HierarchicalNSW<float> *hnsw, int threads = 1) {
+    hnsw->build();
+    char tmpl[] = "/tmp/hnswlib_amd_slim_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) throw std::runtime_error("Cannot open file");
+    close(fd);
+    if (!tmp_path_.empty()) unlink(tmp_path_.c_str());
+    tmp_path_ = tmpl;
+    convertFromHNSW(hnsw, space_, tmp_path_, thr_, p0_, p_, M0h_, m0l_, Mh_, ml_, threads);
+  }
+  // convertFromHNSW + saveIndex to `slim_location`, then load it on the device.
   void convertFromHNSW(HierarchicalNSW<float> *hnsw, SpaceInterface<float> *s, const std::string &slim_location,
                        int threshold_level = 0, float top_degree_percent0 = 0.02f, float top_degree_percent = 0.02f,
                        size_t top_degree_M0 = 32, size_t low_degree_m0 = 8, size_t top_degree_M = 16,
                        size_t low_degree_m = 4, int threads = 1) {
+    hnsw->build();
     detail::check(hs_convert_slim(hnsw->path().c_str(), detail::metric_of(s), detail::dim_of(s), threshold_level,
                                   top_degree_percent0, top_degree_percent, top_degree_M0, low_degree_m0, top_degree_M,
                                   low_degree_m, threads, slim_location.c_str()));
+    const size_t ef_keep = ef_;
     loadIndex(slim_location, s);
+    setEf(ef_keep);
   }
   void addPoint(const void *, labeltype, bool = false) override {
     throw std::runtime_error("HierarchicalNSWSlim does not support addPoint");  // hnswalg_slim.h:149-152
   }
-  void saveIndex(const std::string &) override {
-    throw std::runtime_error("hnswlib_amd: the device index is read-only; the file it was loaded from is unchanged");
+  // saveIndex (hnswalg_slim.h:717-751): the Slim file this object holds (written by convertFromHNSW or loaded), copied
+  void saveIndex(const std::string &location) override {
+    if (path_.empty()) throw std::runtime_error("hnswlib_amd: nothing to save");
+    if (location == path_) return;
+    std::ifstream in(path_, std::ios::binary);
+    std::ofstream out(location, std::ios::binary);
+    if (!in.is_open() || !out.is_open()) throw std::runtime_error("Cannot open file");
+    out << in.rdbuf();
   }
   // searchKnn(q, k, filter) / searchKnn(q, k): hnswalg_slim.h:1783-1905 / 1907-2028
   std::priority_queue<std::pair<float, labeltype>> searchKnn(const void *query_data, size_t k,

@@ -166,6 +166,10 @@ hs_status hs_brute_force_dev(const float *d_base, const uint64_t *d_labels, size
  * labels = row index; threads==1 reproduces the reference's serial build byte for byte. */
 hs_status hs_build_hnsw(const float *base, size_t n, size_t dim, int metric, size_t M, size_t ef_construction,
                         const char *branching_factor, size_t seed, int threads, const char *out_path);
+/* same with external labels: row i is added as addPoint(base + i*dim, labels[i]) (labels must be distinct) */
+hs_status hs_build_hnsw_labeled(const float *base, const uint64_t *labels, size_t n, size_t dim, int metric, size_t M,
+                                size_t ef_construction, const char *branching_factor, size_t seed, int threads,
+                                const char *out_path);
 /* HierarchicalNSWSlim::convertFromHNSW + saveIndex: hnswalg_slim.h:867-1108, 717-751. */
 hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int threshold_level,
                           float top_degree_percent0, float top_degree_percent, size_t top_degree_M0,

@@ -6,6 +6,9 @@
 //   slim  <slim.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32>      : per-query searchKnn + batch
 //   hnsw  <hnsw.bin> <dim> <queries.f32> <nq> <k> <ef> <out.bin>      : priority_queue overload
 //   bf    <base.f32> <dim> <queries.f32> <nq> <k> <n> <out.bin>         : BruteforceSearch addPoint + searchKnn
+//   build <base.f32> <dim> <queries.f32> <nq> <k> <ef> <out.u32> <n> <hnsw_out> <slim_out>   : the build-then-search
+//         sequence of include/strategy/hnsw_strategy.h:24-40 + hnsw_slim_strategy.h:83-103 (ctor, addPoint loop,
+//         saveIndex, convertFromHNSW, saveIndex, setEf, searchKnn)
 //   slimq <slimq.bin> <dim> <queries.f32> <nq> <k> <ef> <out.u32> <base.f32> <n>   : HierarchicalNSWSlimQ, the
 //         call sequence of include/strategy/hnsw_slimq_strategy.h:72,142-156
 #include <cstdio>
@@ -58,6 +61,29 @@ int main(int argc, char **argv) {
   auto Q = read_f32(argv[4], nq * dim);
   hnswlib::L2Space space(dim);
   std::ofstream out(argv[8], std::ios::binary);
+  if (mode == "build") {
+    if (argc < 12) return 2;
+    const size_t n = atoll(argv[9]);
+    auto B = read_f32(path, n * dim);
+    hnswlib::HierarchicalNSW<float> hnsw(&space, n, 16, 100, "4");
+    for (size_t i = 0; i < n; i++) hnsw.addPoint(B.data() + i * dim, i);
+    hnsw.saveIndex(argv[10]);
+    hnswlib::HierarchicalNSWSlim<float> slim(&space, n, 16, 100);
+    slim.convertFromHNSW(&hnsw);
+    slim.saveIndex(argv[11]);
+    slim.setEf(ef);
+    slim.setExactOrder(true);
+    std::vector<hnswlib::tableint> one(k);
+    for (size_t i = 0; i < nq; i++) {
+      slim.searchKnn(Q.data() + i * dim, k, one.data());
+      out.write((char *)one.data(), 4 * k);
+    }
+    // the vanilla object answers too (farthest-first priority_queue)
+    auto r = hnsw.searchKnn(Q.data(), k);
+    uint32_t c = r.size();
+    out.write((char *)&c, 4);
+    return 0;
+  }
   if (mode == "bf") {
     const size_t n = ef;  // 7th argument is the row count in this mode
     auto B = read_f32(path, n * dim);

@@ -218,6 +218,30 @@ def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
     assert rec["p"]["d"].tobytes() == np.ascontiguousarray(w["dists"][:, ::-1]).tobytes()
 
 
+def test_cpp_facade_build_then_search(hs, oracle, tmp_path):
+    """A caller that BUILDS through the hnswlib API (ctor, addPoint loop, saveIndex, convertFromHNSW, saveIndex, setEf,
+    searchKnn -- hnsw_strategy.h / hnsw_slim_strategy.h): the saved files are the harness's (byte-identical to the
+    reference's serial build), the search results the oracle's."""
+    import subprocess
+    from hsutil import ROOT
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "facade_smoke")
+    g = np.load(os.path.join(GOLDEN, "l2_cont_d32.npz"))
+    base, q = np.ascontiguousarray(g["base"][:800]), np.ascontiguousarray(g["queries"][:25])
+    bf, qf, out, hp, sp = (str(tmp_path / f) for f in ("b.f32", "q.f32", "o.bin", "h.bin", "s.bin"))
+    base.tofile(bf); q.tofile(qf)
+    subprocess.check_call([exe, "build", bf, "32", qf, "25", "10", "40", out, "800", hp, sp])
+    mine_h, mine_s = str(tmp_path / "h2.bin"), str(tmp_path / "s2.bin")
+    hs.build_hnsw(base, mine_h, M=16, ef_construction=100, branching_factor="4", seed=100, threads=1)
+    hs.convert_slim(mine_h, mine_s, 32)
+    assert open(hp, "rb").read() == open(mine_h, "rb").read()
+    assert open(sp, "rb").read() == open(mine_s, "rb").read()
+    ox = oracle.load(sp, "slim", L2, 32)
+    ox.set_ef(40)
+    want = ox.search_ids(q, 10)["labels"]
+    raw = np.fromfile(out, np.uint32)
+    assert np.array_equal(raw[:250].reshape(25, 10), want) and raw[250] == 10
+
+
 @pytest.mark.parametrize("name,dim", [("l2_cont_d32_del", 32), ("l2_int_d16_del", 16)])
 def test_delete_marks_vs_compiled_reference(hs, name, dim):
     """Index saved by the reference after markDelete: both kernels take the !bare_bone_search branch."""
