@@ -128,8 +128,8 @@ __device__ __forceinline__ void vis_init(Visited &v, const SearchArgs &a, uint32
 }
 // Call (wave-uniformly) before up to m inserts.  Returns false when even tier 2 is exhausted.
 __device__ __forceinline__ bool vis_reserve(Visited &v, uint32_t m, const SearchArgs &a, int lane) {
-  if (!v.spilled) {
-    if (v.n1 + m <= v.limit1) return true;
+  if (__builtin_expect(!v.spilled, 1)) {
+    if (__builtin_expect(v.n1 + m <= v.limit1, 1)) return true;
     if (!v.t2) return false;
     for (uint32_t i = lane; i < v.slots2; i += 64) v.t2[i] = kEmpty;
     __threadfence_block();
@@ -162,9 +162,9 @@ __device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
     const int e = bucket_scan(w, id);
     if (e == -2) return false;
     if (e >= 0) {
-      if (v.spilled) break;  // tier 1 is frozen: the id is not in it
+      if (__builtin_expect(v.spilled, 0)) break;  // tier 1 is frozen: the id is not in it
       const uint32_t old = atomicCAS(&v.t1[b * 4 + e], kEmpty, id);
-      if (old == kEmpty) return true;
+      if (__builtin_expect(old == kEmpty, 1)) return true;
       if (old == id) return false;
       continue;  // another lane of this wave took the slot: look at the bucket again
     }
@@ -593,7 +593,7 @@ __device__ __forceinline__ void cand_push_t(const CandHeap &h, uint32_t n /*size
   if ((uint32_t)lane == r) ch_set<T2>(h, n >> r, make_uint2(__float_as_uint(d), id));
 }
 __device__ __forceinline__ void cand_push(const CandHeap &h, uint32_t n, float d, uint32_t id, int lane) {
-  if (n < h.L) cand_push_t<false>(h, n, d, id, lane);  // slot n is the deepest slot touched
+  if (__builtin_expect(n < h.L, 1)) cand_push_t<false>(h, n, d, id, lane);  // slot n is the deepest slot touched
   else cand_push_t<true>(h, n, d, id, lane);
 }
 // std::pop_heap (one lane).  Returns nothing; the popped root was read by the caller beforehand.
@@ -627,7 +627,7 @@ __device__ __forceinline__ void cand_pop_t(const CandHeap &h, uint32_t n /*size 
   ch_set<T2>(h, hole + 1, v);
 }
 __device__ __forceinline__ void cand_pop(const CandHeap &h, uint32_t n) {
-  if (n < h.L) cand_pop_t<false>(h, n);
+  if (__builtin_expect(n < h.L, 1)) cand_pop_t<false>(h, n);
   else cand_pop_t<true>(h, n);
 }
 
@@ -729,8 +729,8 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   // smallest distance if that beats the old root, else the old root.  So the next node's adjacency read
   // is issued first and the very same pushes / pop run on the LDS heap while HBM is busy.
   while (true) {
-    if (cand_size == 0 && pending == 0) break;
-    if (bare ? (next_d > lb) : (next_d > lb && top_size == ef)) break;  // :340 / :346-347
+    if (__builtin_expect(cand_size == 0 && pending == 0, 0)) break;
+    if (__builtin_expect(bare ? (next_d > lb) : (next_d > lb && top_size == ef), 0)) break;  // :340 / :346-347
     // the node's whole level-0 list is one aligned tile: one coalesced read from its id
     uint32_t id = kNone;
     if ((uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
@@ -748,8 +748,8 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     const bool valid = id != kNone;
     const uint32_t m = __popcll(__ballot(valid));
     HS_LAP(c, 1);
-    if (!vis_reserve(vis, m, a, lane)) { rc = 1; break; }
-    if (cand_size + m > cand_total) { rc = 2; break; }
+    if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
+    if (__builtin_expect(cand_size + m > cand_total, 0)) { rc = 2; break; }
     bool isnew = false;
     if (valid) isnew = vis_insert(vis, id);  // :392-393
     const unsigned long long nm = __ballot(isnew);
@@ -765,7 +765,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     auto pop_hook = [&]() {
       if (lane == 0) cand_pop(cand, cand_size);
     };
-    if (cnt > 0) {
+    if (__builtin_expect(cnt > 0, 1)) {
       wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane, pop_hook);  // :395-396
     } else {
       pop_hook();
@@ -778,7 +778,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     float best_d = FLT_MAX;
     uint32_t best_id = 0;
     bool have_best = false;
-    if (bare) {
+    if (__builtin_expect(bare, 1)) {
       // ---- accept decisions (:403-452) for the whole tile at once --------------------------------------------
       // The reference scans the new neighbours in adjacency order, accepting j iff top_size < ef || lowerBound > d_j
       // with the result set updated after every acceptance.  Equivalent closed form: with T the result set before
@@ -840,7 +840,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
           best_d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), bl));
           best_id = __builtin_amdgcn_readlane(my_id, bl);
           have_best = true;
-          if (tlog && acc) {
+          if (__builtin_expect(tlog != nullptr, 1) && acc) {
             const uint32_t at = n_log + __popcll(am & ((1ull << lane) - 1ull));
             if (at < a.log_cap) tlog[at] = make_uint2(__float_as_uint(my_d), my_id);
           }
@@ -880,7 +880,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     }
     HS_LAP(c, 4);
   }
-  if (rc != 0) {
+  if (__builtin_expect(rc != 0, 0)) {
     flag_query(a, qi, ST_OVERFLOW, rc - 1, lane);
     return rc;
   }
@@ -889,7 +889,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   //      depend on the LAYOUT of its result heap (nth_element / pop_heap pick among equal keys by position).
   //      The traversal above is already the reference's, so its heap is rebuilt exactly by replaying the logged
   //      insertions through libstdc++'s push_heap/pop_heap mechanics -- in the visited-set area, dead by now.
-  if (top_size > k && top_key_at<S>(tk, k - 1) == top_key_at<S>(tk, k)) {
+  if (__builtin_expect(top_size > k && top_key_at<S>(tk, k - 1) == top_key_at<S>(tk, k), 0)) {
     if (lane == 0) atomicAdd(a.counters + 2, 1u);
     if (!tlog || n_log > a.log_cap) return 3;  // log did not fit: the strict kernel re-runs the query
     Pair *top = reinterpret_cast<Pair *>(hash);
