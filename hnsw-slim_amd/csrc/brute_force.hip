@@ -23,7 +23,6 @@ namespace hs {
 
 static constexpr int kQT = 8;       // queries per workgroup tile
 static constexpr int kWaves = 4;    // waves per workgroup
-static constexpr int kRPL = 1;      // rows per 4-lane group and pass (2 halves the LDS reads but costs a wave of occupancy: slower)
 
 struct BfEntry { float d; uint32_t row; uint64_t label; };   // 16 bytes
 
@@ -49,61 +48,48 @@ __global__ void __launch_bounds__(64 * kWaves) bf_scan_kernel(const float *base,
   uint32_t *msz = sizes + wave * kQT;
   const uint32_t r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
   const uint32_t steps = dim >> 4;
-  // kRPL rows per lane group and pass: every 16-byte piece of a query read from LDS is used against kRPL rows
-  // (measured: kRPL = 2 -> 158 VGPRs, 3 waves/SIMD, 156 ms vs 128 ms at 1M x 10k x 128; kRPL = 1 it is)
-  for (uint32_t rb = r0 + wave * (16 * kRPL); rb < r1; rb += 16 * kRPL * kWaves) {
-    const float4 *x[kRPL];
-    bool act[kRPL];
+  // (two rows per lane group and pass would halve the LDS reads of the queries, but costs 60 VGPRs and a resident
+  // wave: measured 156 ms against 128 ms at 1M x 10k x 128)
+  for (uint32_t rb = r0 + wave * 16; rb < r1; rb += 16 * kWaves) {
+    const uint32_t row = rb + grp;
+    const bool act = row < r1;
+    const float4 *x = reinterpret_cast<const float4 *>(base + (size_t)(act ? row : r0) * dim) + sub;
+    float acc[kQT][4];
 #pragma unroll
-    for (int u = 0; u < kRPL; u++) {
-      const uint32_t row = rb + 16 * u + grp;
-      act[u] = row < r1;
-      x[u] = reinterpret_cast<const float4 *>(base + (size_t)(act[u] ? row : r0) * dim) + sub;
-    }
-    float acc[kRPL][kQT][4];
-#pragma unroll
-    for (int u = 0; u < kRPL; u++)
-#pragma unroll
-      for (int t = 0; t < kQT; t++) acc[u][t][0] = acc[u][t][1] = acc[u][t][2] = acc[u][t][3] = 0.f;
+    for (int t = 0; t < kQT; t++) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
     for (uint32_t s = 0; s < steps; s++) {
-      float4 xv[kRPL];
-#pragma unroll
-      for (int u = 0; u < kRPL; u++) xv[u] = x[u][s * 4];
+      const float4 xv = x[s * 4];
 #pragma unroll
       for (int t = 0; t < kQT; t++) {
         const float4 qv = *reinterpret_cast<const float4 *>(q + (size_t)t * dim + s * 16 + sub * 4);
-#pragma unroll
-        for (int u = 0; u < kRPL; u++) step4<METRIC>(acc[u][t], qv, xv[u]);
+        step4<METRIC>(acc[t], qv, xv);
       }
     }
 #pragma unroll
-    for (int u = 0; u < kRPL; u++) {
-#pragma unroll
-      for (int t = 0; t < kQT; t++) {
-        bool owner;
-        const float d = lane4_reduce<METRIC>(acc[u][t], sub, owner);
-        if (q0 + t >= nq) continue;
-        const uint32_t sz = msz[t];
-        const float thr = sz < k ? FLT_MAX : mine[(size_t)t * k + k - 1].d;
-        unsigned long long m = __ballot(act[u] && owner && d <= thr);   // bruteforce.h:120 `dist <= lastdist`
-        while (m) {
-          const int l = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
-          const uint32_t rj = rb + 16 * u + (uint32_t)(l >> 2);
-          if (lane == 0) {
-            const uint64_t lab = labels ? labels[rj] : (uint64_t)rj;
-            BfEntry *L = mine + (size_t)t * k;
-            uint32_t cur = msz[t];
-            if (cur < k || bf_less(dj, lab, L[k - 1])) {
-              uint32_t pos = cur < k ? cur : k - 1;
-              while (pos > 0 && bf_less(dj, lab, L[pos - 1])) { L[pos] = L[pos - 1]; pos--; }
-              L[pos] = BfEntry{dj, rj, lab};
-              if (cur < k) msz[t] = cur + 1;
-            }
+    for (int t = 0; t < kQT; t++) {
+      bool owner;
+      const float d = lane4_reduce<METRIC>(acc[t], sub, owner);
+      if (q0 + t >= nq) continue;
+      const uint32_t sz = msz[t];
+      const float thr = sz < k ? FLT_MAX : mine[(size_t)t * k + k - 1].d;
+      unsigned long long m = __ballot(act && owner && d <= thr);   // bruteforce.h:120 `dist <= lastdist`
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
+        const uint32_t rj = rb + (uint32_t)(l >> 2);
+        if (lane == 0) {
+          const uint64_t lab = labels ? labels[rj] : (uint64_t)rj;
+          BfEntry *L = mine + (size_t)t * k;
+          uint32_t cur = msz[t];
+          if (cur < k || bf_less(dj, lab, L[k - 1])) {
+            uint32_t pos = cur < k ? cur : k - 1;
+            while (pos > 0 && bf_less(dj, lab, L[pos - 1])) { L[pos] = L[pos - 1]; pos--; }
+            L[pos] = BfEntry{dj, rj, lab};
+            if (cur < k) msz[t] = cur + 1;
           }
-          wave_sync();
         }
+        wave_sync();
       }
     }
   }
@@ -169,8 +155,8 @@ size_t bf_partial_bytes(uint32_t n, uint32_t nq, uint32_t k, uint32_t *grid_x, u
   uint32_t gx = (1024 + tiles - 1) / tiles;
   gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
   uint32_t rpb = (n + gx - 1) / gx;
-  rpb = (rpb + 127) / 128 * 128;
-  if (rpb == 0) rpb = 128;
+  rpb = (rpb + 63) / 64 * 64;
+  if (rpb == 0) rpb = 64;
   gx = (n + rpb - 1) / rpb;
   if (gx == 0) gx = 1;
   *grid_x = gx;

@@ -62,11 +62,25 @@ inline float ip_row16(const float *q, const float *x, size_t d) {
 // elements + scalar L2Sqr on the rest (:149-160); dim>4 -> SIMD4 + scalar rest (:192-205); else scalar (:6-20).
 // One thread does a whole row: usable per lane on the device (runtime-dim kernels) and by the host builder.
 HS_HD float l2_part16(const float *q, const float *x, uint32_t d16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device (rare, runtime-dim path): one lane accumulator at a time -- the same additions in the same order (acc_j over
+  // the steps, then acc_0 + acc_1 + ... left to right) with two live registers instead of sixteen, so that this
+  // fallback does not set the register budget (= resident waves) of the kernels it is compiled into.
+  float r = 0.f;
+  for (uint32_t j = 0; j < 16; j++) {
+    float a = 0.f;
+    for (uint32_t s = 0; s < d16; s += 16) {
+      const float t = q[s + j] - x[s + j];
+      const float p = t * t;
+      a = a + p;
+    }
+    r = j == 0 ? a : r + a;
+  }
+  return r;
+#else
   float acc[16];
-#pragma unroll
   for (int j = 0; j < 16; j++) acc[j] = 0.f;
   for (uint32_t s = 0; s < d16; s += 16) {
-#pragma unroll
     for (int j = 0; j < 16; j++) {
       const float t = q[s + j] - x[s + j];
       const float p = t * t;
@@ -74,9 +88,9 @@ HS_HD float l2_part16(const float *q, const float *x, uint32_t d16) {
     }
   }
   float r = acc[0];
-#pragma unroll
   for (int j = 1; j < 16; j++) r = r + acc[j];
   return r;
+#endif
 }
 HS_HD float l2_part4(const float *q, const float *x, uint32_t d4) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f};

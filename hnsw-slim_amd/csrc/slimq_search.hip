@@ -501,7 +501,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         // Full heap, no two equal keys in it, new key strictly above the root: push_heap lifts the new element to the
         // root along its leaf-to-root path and pop_heap's sift-down retraces exactly that path (every path element is
         // strictly larger than its sibling), leaving the array as it was -- skip the emulation.
-        if (__builtin_expect(hn == a.k && !heap_dup && dj > heap_root, 1)) continue;
+        if (hn == a.k && !heap_dup && dj > heap_root) continue;
         heap_dup = heap_dup || __ballot((uint32_t)lane < hn && hkey == dj) != 0ull;
         rh[hn++] = Pair{dj, uni(pend[j])};
         push_heap(rh, (long)hn, LessD());
@@ -524,13 +524,13 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   while (ps.cur != kNoRank) {
     const uint32_t node = pool_pop<S>(pval, ps, lane);
     const bool seen = set_has(tab, mask, node);
-    if (__builtin_expect(a.trace != nullptr, 0) && lane == 0 && n_tr + 1 < a.trace_cap) {
+    if (a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
       a.trace[(size_t)qi * a.trace_cap + n_tr] = node | (seen ? kChecked : 0u);
       a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = ps.size;
     }
     n_tr += 2;
     if (seen) { n_rev++; continue; }                                 // :700-702
-    if (__builtin_expect((n_set + 1) * 4 > a.hash_slots * 3, 0)) { rc = ST_OVERFLOW; break; }
+    if ((n_set + 1) * 4 > a.hash_slots * 3) { rc = ST_OVERFLOW; break; }
     wave_sync();
     if (lane == 0) set_add(tab, mask, node);                         // :704
     n_set++;
@@ -550,14 +550,14 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         if (dj > ps.last) continue;                       // is_full(), :741
         pool_insert<S>(pkey, pval, ps, dj, cj, lane);      // :745
         n_ins++;
-        if (__builtin_expect(a.trace != nullptr, 0) && lane == 0 && n_tr + 1 < a.trace_cap) {
+        if (a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
           a.trace[(size_t)qi * a.trace_cap + n_tr] = cj | 0x40000000u;
           a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = __float_as_uint(dj);
         }
         n_tr += 2;
       }
     };
-    if (__builtin_expect(sq.ftile != nullptr, 1)) {
+    if (sq.ftile) {
       // fused level-0 tile: slot j of node's row IS neighbour j's record, its header's 4th word the neighbour id
       // (0xFFFFFFFF = empty slot) -- one dependent HBM access per expansion instead of ids-then-records
       const uint32_t *row = sq.ftile + (size_t)node * ((size_t)ix.tile_stride * sq.rec_words);

@@ -123,3 +123,27 @@ def test_facade_error_conventions(hs):
     subprocess.check_call(["make", "-C", os.path.dirname(exe), "facade_smoke"])
     out = subprocess.run([exe, "errors"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_hot_kernels_keep_their_wave_budget():
+    """Register pressure is part of the design: the hot kernels must stay at their resident-wave budgets without
+    scratch (measured: one wave less per SIMD costs 10-25 % of throughput).  Read from the compiler's report."""
+    import re
+    path = os.path.join(ROOT, "hnsw-slim_amd", "resource_usage.txt")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.dirname(path), "-B", "libhnsw_slim_amd.so"])
+    txt = open(path).read()
+    kern = {}
+    for m in re.finditer(r"Function Name: (\S+)\s+VGPRs: (\d+)\s+ScratchSize \[bytes/lane\]: (\d+)\s+Occupancy \[waves/SIMD\]: (\d+)", txt):
+        kern[m.group(1)] = (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+    want = {
+        "_ZN2hs11fast_kernelILi0ELi1ELi8EEEvNS_8DevIndexENS_10SearchArgsE": 4,   # d=128 L2, ef <= 64
+        "_ZN2hs11fast_kernelILi0ELi2ELi8EEEvNS_8DevIndexENS_10SearchArgsE": 4,   # d=128 L2, ef <= 128 (the bench point)
+        "_ZN2hs12slimq_kernelILi0ELi2ELi2EEEvNS_8DevIndexENS_8DevSlimQENS_9SlimQArgsE": 7,
+        "_ZN2hs12slimq_kernelILi0ELi4ELi2EEEvNS_8DevIndexENS_8DevSlimQENS_9SlimQArgsE": 7,
+        "_ZN2hs14bf_scan_kernelILi0EEEvPKfPKmjjS2_jjjPNS_7BfEntryE": 5,
+    }
+    for name, waves in want.items():
+        assert name in kern, f"{name} missing from resource_usage.txt"
+        vgpr, scratch, occ = kern[name]
+        assert occ >= waves and scratch == 0, f"{name}: {vgpr} VGPRs, {scratch} B scratch, {occ} waves/SIMD (budget {waves})"
