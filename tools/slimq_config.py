@@ -16,7 +16,7 @@ if which == "sift":
     n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 128, 10000, 0
     gen = lambda m, seed: headline_data(m, d, seed)
 else:
-    n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 768, 1000, 1
+    n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 768, 10000, 1
     def gen(m, seed):
         x = sift_like(m, d, seed, n_clusters=4096, rank=12, sigma_sub=40.0, sigma_iso=1.0, integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
