@@ -403,9 +403,13 @@ hs_status hs_index_info(const hs_index *ix, hs_info *out) {
   return HS_OK;
 }
 
-static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k, int mode, uint32_t *l32,
-                            uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, Pair *raw, uint32_t *rawsz,
-                            hipStream_t stream) {
+// One launch group serves at most kMaxLaunchQueries queries: the per-query scratch in global memory (96 KiB each) is
+// sized for that many, larger batches run as consecutive groups on the same stream (counters accumulate).
+static constexpr size_t kMaxLaunchQueries = 32768;
+
+static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, size_t k, int mode, uint32_t *l32,
+                                  uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, Pair *raw, uint32_t *rawsz,
+                                  hipStream_t stream, bool first_group, size_t nq_total) {
   if (!ix) return fail(HS_ERR_INVALID, "null index");
   if (k == 0) return fail(HS_ERR_INVALID, "k must be > 0");
   if (mode != HS_MODE_SLIM_IDS && mode != HS_MODE_PQ) return fail(HS_ERR_INVALID, "bad mode");
@@ -423,8 +427,8 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
   HIP_TRY(w->spill.ensure(nq * (size_t)kSpillStride));
   HIP_TRY(w->counters.ensure(12));
   HIP_TRY(hipMemsetAsync(w->status.p, 0, nq * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
-  w->last_nq = nq;
+  if (first_group) HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
+  w->last_nq = nq_total;
   SearchArgs a{};
   a.queries = d_q; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.ef = sh.ef;
   a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.mode = mode;
@@ -451,6 +455,22 @@ static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k,
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
     a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));
+  }
+  return HS_OK;
+}
+
+static hs_status search_dev(hs_index *ix, const float *d_q, size_t nq, size_t k, int mode, uint32_t *l32,
+                            uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, Pair *raw, uint32_t *rawsz,
+                            hipStream_t stream) {
+  if (!ix) return fail(HS_ERR_INVALID, "null index");
+  if (nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "nq too large");
+  const size_t dim = ix->info.dim, ef = std::max(ix->ef, k);
+  for (size_t off = 0; off < nq || off == 0; off += kMaxLaunchQueries) {
+    const size_t m = std::min(kMaxLaunchQueries, nq - off);
+    hs_status s = search_dev_group(ix, d_q + off * dim, m, k, mode, l32 ? l32 + off * k : nullptr, l64 ? l64 + off * k : nullptr,
+                                   dd ? dd + off * k : nullptr, cnt ? cnt + off : nullptr, stats ? stats + off * 4 : nullptr,
+                                   raw ? raw + off * ef : nullptr, rawsz ? rawsz + off : nullptr, stream, off == 0, nq);
+    if (s != HS_OK || nq == 0) return s;
   }
   return HS_OK;
 }

@@ -218,6 +218,24 @@ def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
     assert rec["p"]["d"].tobytes() == np.ascontiguousarray(w["dists"][:, ::-1]).tobytes()
 
 
+def test_large_batch_runs_as_launch_groups(hs, oracle, tmp_path):
+    """More queries than one launch group holds (32768): consecutive groups on the stream, same answers."""
+    base = mixture(3000, 32, 81, integer=True)
+    q = mixture(70001, 32, 82, integer=True)
+    hp, sp = str(tmp_path / "h.bin"), str(tmp_path / "s.bin")
+    hs.build_hnsw(base, hp, M=8, ef_construction=60, threads=8)
+    hs.convert_slim(hp, sp, 32, threads=8)
+    ix = hs.Index(sp, hs.HS_KIND_SLIM, 32)
+    ox = oracle.load(sp, "slim", L2, 32)
+    ix.set_ef(40); ox.set_ef(40)
+    got = ix.search_ids(q, 10, want_stats=True)
+    want = ox.search_ids(q, 10, threads=8)
+    assert np.array_equal(np.sort(got["labels"], axis=1), np.sort(want["labels"], axis=1))
+    assert np.array_equal(got["stats"][:, :3], want["counters"][:, :3])
+    pq, wq = ix.search_pq(q[32000:33500], 10), ox.search_pq(q[32000:33500], 10, threads=8)
+    assert _pq_sorted(pq["dists"], pq["labels"], pq["cnt"]) == _pq_sorted(wq["dists"], wq["labels"], wq["cnt"])
+
+
 def test_cpp_facade_build_then_search(hs, oracle, tmp_path):
     """A caller that BUILDS through the hnswlib API (ctor, addPoint loop, saveIndex, convertFromHNSW, saveIndex, setEf,
     searchKnn -- hnsw_strategy.h / hnsw_slim_strategy.h): the saved files are the harness's (byte-identical to the
