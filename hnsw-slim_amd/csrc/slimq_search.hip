@@ -524,13 +524,13 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   while (ps.cur != kNoRank) {
     const uint32_t node = pool_pop<S>(pval, ps, lane);
     const bool seen = set_has(tab, mask, node);
-    if (a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
+    if (__builtin_expect(a.trace != nullptr, 0) && lane == 0 && n_tr + 1 < a.trace_cap) {
       a.trace[(size_t)qi * a.trace_cap + n_tr] = node | (seen ? kChecked : 0u);
       a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = ps.size;
     }
     n_tr += 2;
     if (seen) { n_rev++; continue; }                                 // :700-702
-    if ((n_set + 1) * 4 > a.hash_slots * 3) { rc = ST_OVERFLOW; break; }
+    if (__builtin_expect((n_set + 1) * 4 > a.hash_slots * 3, 0)) { rc = ST_OVERFLOW; break; }
     wave_sync();
     if (lane == 0) set_add(tab, mask, node);                         // :704
     n_set++;
@@ -550,14 +550,14 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         if (dj > ps.last) continue;                       // is_full(), :741
         pool_insert<S>(pkey, pval, ps, dj, cj, lane);      // :745
         n_ins++;
-        if (a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
+        if (__builtin_expect(a.trace != nullptr, 0) && lane == 0 && n_tr + 1 < a.trace_cap) {
           a.trace[(size_t)qi * a.trace_cap + n_tr] = cj | 0x40000000u;
           a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = __float_as_uint(dj);
         }
         n_tr += 2;
       }
     };
-    if (sq.ftile) {
+    if (__builtin_expect(sq.ftile != nullptr, 1)) {
       // fused level-0 tile: slot j of node's row IS neighbour j's record, its header's 4th word the neighbour id
       // (0xFFFFFFFF = empty slot) -- one dependent HBM access per expansion instead of ids-then-records
       const uint32_t *row = sq.ftile + (size_t)node * ((size_t)ix.tile_stride * sq.rec_words);
