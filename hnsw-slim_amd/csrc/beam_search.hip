@@ -964,8 +964,21 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
 template <int METRIC>
 __global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
-    if (!((1u << a.status[qi]) & a.select_mask)) continue;
+  if (a.pass_id != 0) {
+    // re-run passes: 64 statuses per read, then the (normally zero) flagged queries of the block one after the other
+    for (uint32_t base = blockIdx.x * 64; base < a.nq; base += gridDim.x * 64) {
+      const uint32_t q = base + threadIdx.x;
+      unsigned long long m = __ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
+      while (m) {
+        const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
+        m &= m - 1;
+        search_one_strict<METRIC>(ix, a, qi, smem);
+        wave_sync();
+      }
+    }
+    return;
+  }
+  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {  // pass 0 takes every query
     if (ix.n == 0) {  // cur_element_count == 0 (hnswalg_slim.h:2031-2032)
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
       continue;
@@ -979,7 +992,7 @@ template <int METRIC, int S, int D16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
-    if (!((1u << a.status[qi]) & a.select_mask)) continue;
+    if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;  // pass 0 takes every query
     if (ix.n == 0) {
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
       continue;

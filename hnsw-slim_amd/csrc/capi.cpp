@@ -426,7 +426,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   HIP_TRY(w->status.ensure(nq));
   HIP_TRY(w->spill.ensure(nq * (size_t)kSpillStride));
   HIP_TRY(w->counters.ensure(12));
-  HIP_TRY(hipMemsetAsync(w->status.p, 0, nq * sizeof(uint32_t), stream));
+  // (status needs no clearing: pass 0 takes every query and writes each one's final status)
   if (first_group) HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
   w->last_nq = nq_total;
   SearchArgs a{};
@@ -451,7 +451,9 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   }
   // pass 2: queries that outgrew their scratch -> strict kernel with a whole CU's LDS each
   if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
-    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256);
+    // few workgroups: each needs a whole CU's LDS, i.e. a CU drained of every other wave before it can start -- with
+    // several batches in flight a wide grid of them stalls the stream even when (as usual) no query is flagged
+    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 16);
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
     a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));
