@@ -602,8 +602,7 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   hs_index::StreamWs *w = ix->stream_ws(stream);
   HIP_TRY(w->status.ensure(nq));
   HIP_TRY(w->counters.ensure(12));
-  HIP_TRY(hipMemsetAsync(w->status.p, 0, nq * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));   // status: written for every query by the first pass
   w->last_nq = nq;
   SlimQArgs a{};
   a.queries = d_queries; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.pool_cap = (uint32_t)ix->ef;
@@ -621,7 +620,7 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p;
   HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
   if (a.hash_slots < kSlimQMaxHash) {
-    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.hash_slots = kSlimQMaxHash;
+    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 64); a.hash_slots = kSlimQMaxHash;
     a.counters = w->counters.p + 8;
     HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
   }

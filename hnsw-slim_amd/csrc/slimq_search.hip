@@ -610,10 +610,20 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
 template <int METRIC, int S, int NBLK>
 __global__ void __launch_bounds__(64) slimq_kernel(DevIndex ix, DevSlimQ sq, SlimQArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
-    if (!((1u << a.status[qi]) & a.select_mask)) continue;
-    slimq_one<METRIC, S, NBLK>(ix, sq, a, qi, smem);
+  if (a.select_mask != (1u << ST_TODO)) {
+    // second pass: 64 statuses per read, then the (normally zero) flagged queries of the block one after the other
+    for (uint32_t base = blockIdx.x * 64; base < a.nq; base += gridDim.x * 64) {
+      const uint32_t q = base + threadIdx.x;
+      unsigned long long m = __ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
+      while (m) {
+        const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
+        m &= m - 1;
+        slimq_one<METRIC, S, NBLK>(ix, sq, a, qi, smem);
+      }
+    }
+    return;
   }
+  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) slimq_one<METRIC, S, NBLK>(ix, sq, a, qi, smem);   // first pass: every query
 }
 
 template <typename K>
