@@ -239,16 +239,20 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
         for (int i = 0; i < T; i++) step4<METRIC>(acc, qq[(R * B + i) * 4], buf[i]);
       }
     } else {
+      // runtime dim: the same rounds of up to eight loads in flight, trip counts known only at run time
       const uint32_t steps = ix.dim >> 4;
       const float4 *row = reinterpret_cast<const float4 *>(ix.vec + (size_t)id * ix.dim) + sub;
-      float4 buf[2];  // every supported dim has steps >= 1; first chunk of up to two loads goes out early
-      buf[0] = row[0];
-      buf[1] = steps > 1 ? row[4] : buf[0];
-      if (base == 0) between();
-      step4<METRIC>(acc, qq[0], buf[0]);
-      if (steps > 1) step4<METRIC>(acc, qq[4], buf[1]);
-#pragma unroll 6
-      for (uint32_t s2 = 2; s2 < steps; s2++) step4<METRIC>(acc, qq[s2 * 4], row[s2 * 4]);
+      for (uint32_t r0 = 0; r0 < steps; r0 += 8) {
+        const uint32_t nb = min(8u, steps - r0);
+        float4 buf[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++)
+          if (i < nb) buf[i] = row[(r0 + i) * 4];
+        if (base == 0 && r0 == 0) between();
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++)
+          if (i < nb) step4<METRIC>(acc, qq[(r0 + i) * 4], buf[i]);
+      }
     }
     bool owner;
     const float r = lane4_reduce<METRIC>(acc, sub, owner);
@@ -975,29 +979,30 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
 
 // ---- kernels: grid-stride over the queries selected by status ----------------------------------------
 template <int METRIC>
-__global__ void __launch_bounds__(64) strict_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) strict_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if (a.pass_id != 0) {
-    // re-run passes: 64 statuses per read, then the (normally zero) flagged queries of the block one after the other
-    for (uint32_t base = blockIdx.x * 64; base < a.nq; base += gridDim.x * 64) {
+  // pass 0: one query per workgroup, every query.  Re-run passes: 64 statuses per read, then the (normally zero) flagged
+  // queries of the block one after the other.  (One call site, so that the search body is inlined and the kernel
+  // arguments stay in scalar registers.)
+  const bool scan = a.pass_id != 0;
+  for (uint32_t it = blockIdx.x;; it += gridDim.x) {
+    const uint32_t base = scan ? it * 64 : it;
+    if (base >= a.nq) break;
+    unsigned long long m = 1ull;
+    if (scan) {
       const uint32_t q = base + threadIdx.x;
-      unsigned long long m = __ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
-      while (m) {
-        const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
-        m &= m - 1;
-        search_one_strict<METRIC>(ix, a, qi, smem);
-        wave_sync();
+      m = __ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
+    }
+    while (m) {
+      const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (ix.n == 0) {  // cur_element_count == 0 (hnswalg_slim.h:2031-2032)
+        if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
+        continue;
       }
+      search_one_strict<METRIC>(ix, a, qi, smem);
+      wave_sync();
     }
-    return;
-  }
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {  // pass 0 takes every query
-    if (ix.n == 0) {  // cur_element_count == 0 (hnswalg_slim.h:2031-2032)
-      if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
-      continue;
-    }
-    search_one_strict<METRIC>(ix, a, qi, smem);
-    wave_sync();
   }
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
