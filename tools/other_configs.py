@@ -14,7 +14,7 @@ if which == "gist":
     n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 960, 1000
     gen = lambda m, seed: np.clip(sift_like(m, d, seed, n_clusters=1024, rank=24, sigma_sub=40.0, sigma_iso=3.0, integer=False) / 255.0, 0, 1).astype(np.float32)
 else:
-    n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000, 96, 10000
+    n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000, int(os.environ.get("DIM", "96")), 10000
     def gen(m, seed):
         x = sift_like(m, d, seed, n_clusters=8192, rank=12, sigma_sub=40.0, sigma_iso=4.0, integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
