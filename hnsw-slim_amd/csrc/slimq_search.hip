@@ -35,6 +35,7 @@ namespace hs {
 
 static constexpr uint32_t kNoneQ = 0xFFFFFFFFu;
 static constexpr uint32_t kChecked = 0x80000000u;
+static constexpr int kRR = 4;   // re-rank: 16-byte loads in flight per lane
 
 __host__ __device__ inline uint32_t al16(uint32_t x) { return (x + 15u) & ~15u; }
 
@@ -486,8 +487,17 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const uint32_t steps = ix.dim >> 4;
-#pragma unroll 1
-    for (uint32_t s2 = 0; s2 < steps; s2++) step4<METRIC>(acc, qq[s2 * 4], row[s2 * 4]);
+    // rounds of kRR 16-byte loads in flight per lane (one load per iteration would serialise the HBM latency)
+    for (uint32_t r0 = 0; r0 < steps; r0 += kRR) {
+      const uint32_t nb = min((uint32_t)kRR, steps - r0);
+      float4 buf[kRR];
+#pragma unroll
+      for (uint32_t i = 0; i < kRR; i++)
+        if (i < nb) buf[i] = row[(r0 + i) * 4];
+#pragma unroll
+      for (uint32_t i = 0; i < kRR; i++)
+        if (i < nb) step4<METRIC>(acc, qq[(r0 + i) * 4], buf[i]);
+    }
     bool owner;
     const float r = lane4_reduce<METRIC>(acc, sub, owner);
     if (act && owner) pd[grp] = r;
