@@ -390,21 +390,23 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   for (uint32_t i = lane; i < sq.ncl; i += 64) gadd[i] = __uint_as_float(pr[4 + i]);
   const float delta = __uint_as_float(uni(pr[0])), vl = __uint_as_float(uni(pr[1])), k1 = __uint_as_float(uni(pr[2]));
   const uint64_t *planes_g = reinterpret_cast<const uint64_t *>(pr + prep_planes_off(sq.ncl));
-  if (NBLK == 0) {
+  constexpr bool kScalarPlanes = NBLK > 0 && NBLK <= 2;
+  if (!kScalarPlanes) {
 #pragma unroll 1
     for (uint32_t i = lane; i < P / 64 * 4; i += 64) planes_lds[i] = planes_g[i];
   }
   wave_sync();
-  // short codes: the query's bit planes are wave-uniform -> keep them in SGPRs (no LDS reads in the estimator)
-  uint64_t upl[NBLK > 0 ? NBLK * 4 : 1];
-  if (NBLK > 0) {
+  // short codes: the query's bit planes are wave-uniform -> keep them in SGPRs (no LDS reads in the estimator);
+  // longer compile-time codes (d = 768: 12 words) keep the planes in LDS but load the whole sign code up front
+  uint64_t upl[kScalarPlanes ? NBLK * 4 : 1];
+  if (kScalarPlanes) {
 #pragma unroll
     for (int i = 0; i < NBLK * 4; i++) {
       const uint64_t v = planes_g[i];
       upl[i] = (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
     }
   }
-  const uint64_t *planes = NBLK > 0 ? upl : planes_lds;
+  const uint64_t *planes = kScalarPlanes ? upl : planes_lds;
 
   uint32_t n_hops = 0, n_est = 1, n_ins = 0, n_rev = 0, n_tr = 0;
   // entry point and greedy descent on estimated distances (:1850-1901)
@@ -658,8 +660,10 @@ hipError_t launch_slimq(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs 
   const size_t lds = slimq_lds_bytes(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
   if (ix.metric == METRIC_L2) {
     if (sq.padded == 128) return launch_ms<METRIC_L2, 2>(ix, sq, a, lds, stream);
+    if (sq.padded == 768) return launch_ms<METRIC_L2, 12>(ix, sq, a, lds, stream);
     return launch_ms<METRIC_L2, 0>(ix, sq, a, lds, stream);
   }
+  if (sq.padded == 768) return launch_ms<METRIC_IP, 12>(ix, sq, a, lds, stream);   // COHERE / text embeddings
   return launch_ms<METRIC_IP, 0>(ix, sq, a, lds, stream);
 }
 
