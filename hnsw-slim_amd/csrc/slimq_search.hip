@@ -183,7 +183,25 @@ __device__ __forceinline__ float est_rec(const DevSlimQ &sq, const uint64_t *pla
     }
     ipq = rq_ip_x0_qr(x, planes, NBLK, delta, vl);
   } else {
-    ipq = rq_ip_x0_qr(code, planes, sq.padded >> 6, delta, vl);
+    // runtime code length: four 8-byte words in flight per round (integer sums, so the grouping changes nothing)
+    const uint32_t nblk = sq.padded >> 6;
+    uint32_t ip = 0, pc = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 4) {
+      const uint32_t nb = min(4u, nblk - b0);
+      uint64_t x[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++)
+        if (i < nb) x[i] = code[b0 + i];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++)
+        if (i < nb) {
+          pc += rq_popc64(x[i]);
+#pragma unroll
+          for (int j = 0; j < 4; j++) ip += (uint32_t)rq_popc64(x[i] & planes[(b0 + i) * 4 + j]) << j;
+        }
+    }
+    const float a1 = delta * (float)ip, c1 = vl * (float)pc;   // rq_ip_x0_qr's fp32 expression
+    ipq = a1 + c1;
   }
   return rq_est_dist(__uint_as_float(h.x), gadd[h.z], __uint_as_float(h.y), ipq, k1);
 }
