@@ -11,17 +11,23 @@
 //       get_bin_est -> split_single_estdist           hnswlib/hnswalg_slimq.h:408-440, rabitqlib/index/estimator.hpp:164-188
 //       exact rerank + k-bounded max-heap             hnswlib/hnswalg_slimq.h:747-757
 //
-// Mapping to the wavefront:
-//   * Query preparation runs in LDS: the Hadamard butterflies are element-wise (bit-exact in any lane order);
-//     the float reductions are plain left-to-right sums (the definition rabitq_host.hpp documents), one
-//     reduction per lane, all of them in flight together.
-//   * The SearchBuffer (sorted array, capacity ef) lives in registers: rank r in lane r%64, slot r/64.  Lower-bound
-//     position = popcount of a ballot, the memmove = one DPP wave_shr per slot, pop = ffs of the unchecked ballot.
-//   * One lane per neighbour: a RaBitQ record is 16 B of factors + padded/8 B of sign code (32 B at d=128), the
-//     estimator is AND + popcount against the query's 4 bit planes (LDS broadcast reads).  Candidates that survive
-//     the (monotone) is_full pre-test are inserted in adjacency order, as the reference's scan does.
-//   * Exact reranks are batched 16 at a time (4 lanes per row, the distance recipe of dist_recipe.hpp) and pushed
-//     into the k-heap in expansion order, so the heap array ends up as the reference's.
+// Two kernels, one wavefront per query each:
+//   * slimq_prep_kernel: query preparation in LDS.  The Hadamard butterflies are element-wise (bit-exact in any lane
+//     order); the float reductions are plain left-to-right sums (the definition rabitq_host.hpp documents), one
+//     reduction per lane, all of them in one loop.  Output: a small per-query record (delta, vl, k1xsumq, g_add per
+//     cluster, bit planes).  Kept apart so that the search kernel's registers and LDS are sized by the traversal.
+//   * slimq_kernel: the traversal.
+//     - The SearchBuffer (sorted array, capacity ef) lives in registers: rank r in lane r%64, slot r/64, +inf/checked
+//       padding.  Lower-bound position = popcount of a ballot per slot, the memmove = one DPP wave_shr per slot at or
+//       behind the insertion point (wave-uniform branches skip the others), cur_ and the last key are scalars.
+//     - Level 0 and the upper levels are read from FUSED tiles: slot j of a node's tile is neighbour j's whole RaBitQ
+//       record (16 B of factors + padded/8 B of sign code, 32 B at d=128) with the neighbour id in the header -- one
+//       dependent HBM access per expansion.  One lane per neighbour; the estimator is AND + popcount against the
+//       query's 4 bit planes (SGPRs for codes of <= 2 words, LDS otherwise; compile-time code lengths load the whole
+//       code up front).  Candidates that survive the (monotone) is_full pre-test are inserted in adjacency order.
+//     - Exact re-ranks are batched 16 at a time (4 lanes per row, the distance recipe of dist_recipe.hpp) and pushed
+//       into the k-heap (registers, element j in lane j) in expansion order, so the heap array ends up as the
+//       reference's; a push that provably leaves the array untouched is skipped.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
