@@ -11,24 +11,30 @@
 //   VisitedList                                visited_list_pool.h:10-31 (exact, as an LDS hash set)
 //
 // Design (MI355X-first, gather-bound -> no MFMA):
-//   * adjacency: CSR in HBM (all levels) plus, for level 0, one aligned tile of ids per node so that an
-//     expansion is ONE coalesced 64..256-byte read issued straight from the popped id;
-//   * visited set: open-addressing hash of 32-bit ids in LDS (exact: a false positive would change
-//     results); lanes insert their neighbour id with ds_cmpst, the ballot of "newly inserted" gives the
+//   * adjacency: CSR in HBM (all levels) plus one aligned tile of ids per node for level 0 (an expansion is ONE
+//     coalesced 64..256-byte read issued straight from the popped id) and {id, up_base} tiles for the upper levels
+//     (a descent step is tile -> rows, two dependent accesses);
+//   * visited set: bucketed hash of 32-bit ids in LDS (exact: a false positive would change results) with a second
+//     tier in global memory; lanes insert their neighbour id with ds_cmpst, the ballot of "newly inserted" gives the
 //     unvisited list in adjacency order;
 //   * distances: 4 lanes per neighbour row, 16 rows per pass; lane `sub` loads the 16-byte chunk
 //     16*s+4*sub of every 64-byte step and owns AVX-512 lane accumulators 4*sub..4*sub+3, so the fp32
-//     sum is formed in exactly the reference's order (dist_recipe.hpp) -> bit-identical distances;
+//     sum is formed in exactly the reference's order (dist_recipe.hpp) -> bit-identical distances; rounds of eight
+//     loads in flight per lane, compile-time dims for the common shapes; dim % 16 != 0 runs the reference's
+//     SIMD4 / residual recipes one lane per row;
 //   * candidate heap: the reference's raw array in LDS with libstdc++'s push_heap/pop_heap sift sequence
-//     applied by lane 0 -> the expansion order among equal-distance candidates is the reference's;
+//     (push: the whole wave in one read/write round; pop: lane 0) -> the expansion order among equal-distance
+//     candidates is the reference's;
 //   * result set, two kernels:
 //       strict: the reference's raw top_candidates array + libstdc++ heap/nth_element mechanics
 //               (heap_emul.hpp) -> identical array, identical output ORDER, any tie pattern;
-//       fast  : a sorted array held in registers (rank r in lane r%64), insertion = ballot + one DPP
-//               wave shift; which of several equal-distance entries survives/gets selected is then not
-//               defined, so a query whose k-subset could depend on it (k-th and (k+1)-th distance equal)
-//               is flagged ST_HAZARD and answered by the strict kernel.  Output sorted by distance.
-//   * a query that outgrows its LDS scratch is flagged ST_OVERFLOW and re-run by the strict kernel with
+//       fast  : a sorted array held in registers (rank r in lane r%64); a tile's accept decisions are taken at once
+//               from a closed form of the reference's sequential scan and the accepted entries merged in one pass;
+//               which of several equal-distance entries survives/gets selected is then not defined, so for a query
+//               whose k-subset could depend on it (k-th and (k+1)-th distance equal) the logged insertions are
+//               replayed through the libstdc++ mechanics (or, if the log overflowed, the query is flagged ST_HAZARD
+//               and answered by the strict kernel).  Output sorted by distance.
+//   * a query that outgrows even the global-memory tiers is flagged ST_OVERFLOW and re-run by the strict kernel with
 //     a whole CU's LDS.
 #include <hip/hip_runtime.h>
 
