@@ -88,7 +88,7 @@ size_t fast_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t has
   return fast_layout(dim, ef, cand_cap, hash_slots).total;
 }
 bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
-  return ix.tile0 != nullptr && ix.threshold_level == 0 && ef > k && ef <= 512;
+  return ix.tile0 != nullptr && ix.threshold_level == 0 && ef >= k && ef <= 512;
 }
 
 struct Counters {
@@ -744,6 +744,11 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   }
   const uint32_t stride = ix.tile_stride;
   int rc = 0;
+  // ef == k: nothing is selected at the end, so a tie ACROSS the capacity boundary decides the answer -- the reference
+  // evicts the root of its heap, i.e. one of several entries with the largest key, which one depends on the heap layout.
+  // Whenever an evicted key equals the last kept key the logged insertions are replayed (as for the k / k+1 tie).
+  const bool watch_boundary = k == ef;
+  bool boundary_tie = false;
 
   // ---- level-0 beam (hnswalg_slim.h:321-457) -----------------------------------------------------
   // The reference pushes accepted neighbours into candidate_set one by one and pops its root at the top
@@ -837,9 +842,12 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
           for (int s = 0; s < S; s++) shift[s] += tk[s] > dj ? 1u : 0u;
         }
         uint2 *stage = reinterpret_cast<uint2 *>(smem + L.off_stage);
+        const uint32_t old_size = top_size;
+        float drop_k[S];   // keys of old entries pushed beyond the capacity (only looked at when ef == k)
 #pragma unroll
         for (int s = 0; s < S; s++) {
           const uint32_t r = lane + 64 * s, nr = r + shift[s];
+          drop_k[s] = (r < top_size && nr >= ef) ? tk[s] : FLT_MAX;
           if (r < top_size && nr < ef) stage[nr] = make_uint2(__float_as_uint(tk[s]), ti[s]);
         }
         if (acc && A + Bp < ef) stage[A + Bp] = make_uint2(__float_as_uint(my_d), my_id);
@@ -856,6 +864,12 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         }
         wave_sync();
         lb = top_key_at<S>(tk, top_size - 1);  // :450-452
+        if (watch_boundary && old_size + n_acc > ef) {
+          float dropped = (acc && A + Bp >= ef) ? my_d : FLT_MAX;
+#pragma unroll
+          for (int s = 0; s < S; s++) dropped = fminf(dropped, drop_k[s]);
+          boundary_tie = boundary_tie || wave_min_f32(dropped) == lb;
+        }
         pending |= am;
         if (am) {
           // the earliest accepted entry with the smallest distance is the one no accepted entry precedes in (d, j) order
@@ -883,7 +897,10 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         pending |= 1ull << j;
         if (!have_best || d < best_d) { best_d = d; best_id = nb; have_best = true; }
         if (bare || uni(ix.deleted[nb]) == 0) {
+          const bool evicts = top_size == ef;
+          const float evicted = evicts ? top_key_at<S>(tk, ef - 1) : 0.f;   // d < this key (strict), so it is the one dropped
           top_insert<S>(tk, ti, top_size, ef, d, nb, lane);  // :418-448
+          if (watch_boundary && evicts) boundary_tie = boundary_tie || top_key_at<S>(tk, ef - 1) == evicted;
           if (tlog && lane == 0 && n_log < a.log_cap) tlog[n_log] = make_uint2(__float_as_uint(d), nb);
           n_log++;
         }
@@ -912,7 +929,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   //      depend on the LAYOUT of its result heap (nth_element / pop_heap pick among equal keys by position).
   //      The traversal above is already the reference's, so its heap is rebuilt exactly by replaying the logged
   //      insertions through libstdc++'s push_heap/pop_heap mechanics -- in the visited-set area, dead by now.
-  if (__builtin_expect(top_size > k && top_key_at<S>(tk, k - 1) == top_key_at<S>(tk, k), 0)) {
+  if (__builtin_expect((top_size > k && top_key_at<S>(tk, k - 1) == top_key_at<S>(tk, k)) || boundary_tie, 0)) {
     if (lane == 0) atomicAdd(a.counters + 2, 1u);
     if (!tlog || n_log > a.log_cap) return 3;  // log did not fit: the strict kernel re-runs the query
     Pair *top = reinterpret_cast<Pair *>(hash);

@@ -218,6 +218,28 @@ def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
     assert rec["p"]["d"].tobytes() == np.ascontiguousarray(w["dists"][:, ::-1]).tobytes()
 
 
+def test_ef_equal_k_on_the_fast_kernel(hs, oracle, tmp_path):
+    """The reference's defaults (ef_ = 10, K = 10): ef == k, nothing is selected at the end, so ties across the
+    capacity boundary decide the answer -- the fast kernel must notice them and replay (tie-heavy integer data)."""
+    g = np.load(os.path.join(GOLDEN, "l2_int_d16.npz"))
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(os.path.join(GOLDEN, "l2_int_d16.hnsw.bin"), sp, 16)
+    ix = hs.Index(sp, hs.HS_KIND_SLIM, 16)
+    ox = oracle.load(sp, "slim", L2, 16)
+    replays = 0
+    for ef, k in ((10, 10), (5, 32), (64, 64)):
+        ix.set_ef(ef); ox.set_ef(ef)
+        want = ox.search_ids(g["queries"], k)
+        ok = want["raw_sz"] >= k
+        got = ix.search_ids(g["queries"], k, want_stats=True)
+        assert np.array_equal(np.sort(got["labels"][ok], axis=1), np.sort(want["labels"][ok], axis=1)), (ef, k)
+        assert np.array_equal(got["stats"][:, :3], want["counters"][:, :3])
+        replays += int((got["stats"][:, 3] == 1).sum())
+        wp, gp = ox.search_pq(g["queries"], k), ix.search_pq(g["queries"], k)
+        assert _pq_sorted(gp["dists"], gp["labels"], gp["cnt"]) == _pq_sorted(wp["dists"], wp["labels"], wp["cnt"])
+    assert replays > 0, "expected boundary ties on this data"
+
+
 def test_large_batch_runs_as_launch_groups(hs, oracle, tmp_path):
     """More queries than one launch group holds (32768): consecutive groups on the stream, same answers."""
     base = mixture(3000, 32, 81, integer=True)
