@@ -88,7 +88,8 @@ size_t fast_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t has
   return fast_layout(dim, ef, cand_cap, hash_slots).total;
 }
 bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
-  return ix.tile0 != nullptr && ix.threshold_level == 0 && ef >= k && ef <= 512;
+  // ef == k runs the boundary-watching variant, compiled for ef <= 128 only
+  return ix.tile0 != nullptr && ix.threshold_level == 0 && (ef > k || (ef == k && ef <= 128)) && ef <= 512;
 }
 
 struct Counters {
@@ -684,7 +685,7 @@ __device__ __forceinline__ void top_insert(float (&tk)[S], uint32_t (&ti)[S], ui
   size = min(size + 1, ef);
 }
 
-template <int METRIC, int S, int D16>
+template <int METRIC, int S, int D16, bool WB = false>
 __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
   const FastLds L = fast_layout(ix.dim, a.ef, a.cand_cap, a.hash_slots);
@@ -747,7 +748,8 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   // ef == k: nothing is selected at the end, so a tie ACROSS the capacity boundary decides the answer -- the reference
   // evicts the root of its heap, i.e. one of several entries with the largest key, which one depends on the heap layout.
   // Whenever an evicted key equals the last kept key the logged insertions are replayed (as for the k / k+1 tie).
-  const bool watch_boundary = k == ef;
+  // (A separate instantiation: even dormant, this bookkeeping costs the hot kernel 4-5 % -- measured.)
+  constexpr bool watch_boundary = WB;
   bool boundary_tie = false;
 
   // ---- level-0 beam (hnswalg_slim.h:321-457) -----------------------------------------------------
@@ -843,11 +845,18 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         }
         uint2 *stage = reinterpret_cast<uint2 *>(smem + L.off_stage);
         const uint32_t old_size = top_size;
-        float drop_k[S];   // keys of old entries pushed beyond the capacity (only looked at when ef == k)
+        float dropped = FLT_MAX;   // smallest key pushed beyond the capacity (only needed when ef == k)
+        if (watch_boundary) {
+          if (acc && A + Bp >= ef) dropped = my_d;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const uint32_t r = lane + 64 * s;
+            if (r < top_size && r + shift[s] >= ef) dropped = fminf(dropped, tk[s]);
+          }
+        }
 #pragma unroll
         for (int s = 0; s < S; s++) {
           const uint32_t r = lane + 64 * s, nr = r + shift[s];
-          drop_k[s] = (r < top_size && nr >= ef) ? tk[s] : FLT_MAX;
           if (r < top_size && nr < ef) stage[nr] = make_uint2(__float_as_uint(tk[s]), ti[s]);
         }
         if (acc && A + Bp < ef) stage[A + Bp] = make_uint2(__float_as_uint(my_d), my_id);
@@ -864,12 +873,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         }
         wave_sync();
         lb = top_key_at<S>(tk, top_size - 1);  // :450-452
-        if (watch_boundary && old_size + n_acc > ef) {
-          float dropped = (acc && A + Bp >= ef) ? my_d : FLT_MAX;
-#pragma unroll
-          for (int s = 0; s < S; s++) dropped = fminf(dropped, drop_k[s]);
-          boundary_tie = boundary_tie || wave_min_f32(dropped) == lb;
-        }
+        if (watch_boundary && old_size + n_acc > ef) boundary_tie = boundary_tie || wave_min_f32(dropped) == lb;
         pending |= am;
         if (am) {
           // the earliest accepted entry with the smallest distance is the one no accepted entry precedes in (d, j) order
@@ -1029,7 +1033,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
   }
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
-template <int METRIC, int S, int D16>
+template <int METRIC, int S, int D16, bool WB = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
@@ -1038,7 +1042,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fa
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
       continue;
     }
-    const int rc = search_one_fast<METRIC, S, D16>(ix, a, qi, smem);
+    const int rc = search_one_fast<METRIC, S, D16, WB>(ix, a, qi, smem);
     if (rc == 3 && threadIdx.x == 0) a.status[qi] = ST_HAZARD;
     wave_sync();
   }
@@ -1063,6 +1067,10 @@ hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t st
 
 template <int METRIC, int D16>
 static hipError_t launch_fast_md(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
+  if (a.k == a.ef) {  // nothing is selected at the end: the variant that watches ties across the capacity boundary
+    if (a.ef <= 64) return launch(fast_kernel<METRIC, 1, D16, true>, ix, a, lds, stream);
+    return launch(fast_kernel<METRIC, 2, D16, true>, ix, a, lds, stream);
+  }
   if (a.ef <= 64) return launch(fast_kernel<METRIC, 1, D16>, ix, a, lds, stream);
   if (a.ef <= 128) return launch(fast_kernel<METRIC, 2, D16>, ix, a, lds, stream);
   if (a.ef <= 256) return launch(fast_kernel<METRIC, 4, D16>, ix, a, lds, stream);
