@@ -89,7 +89,7 @@ size_t fast_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t has
 }
 bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
   // ef == k runs the boundary-watching variant, compiled for ef <= 128 only
-  return ix.tile0 != nullptr && ix.threshold_level == 0 && (ef > k || (ef == k && ef <= 128)) && ef <= 512;
+  return ix.tile0 != nullptr && ix.threshold_level == 0 && (ef > k || (ef == k && ef <= 128 && !ix.has_deleted)) && ef <= 512;
 }
 
 struct Counters {
@@ -685,7 +685,7 @@ __device__ __forceinline__ void top_insert(float (&tk)[S], uint32_t (&ti)[S], ui
   size = min(size + 1, ef);
 }
 
-template <int METRIC, int S, int D16, bool WB = false>
+template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
 __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
   const FastLds L = fast_layout(ix.dim, a.ef, a.cand_cap, a.hash_slots);
@@ -714,7 +714,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   descend<METRIC, D16>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
   HS_LAP(c, 5);
 
-  const bool bare = !ix.has_deleted;
+  constexpr bool bare = BARE;   // no delete marks / filter anywhere in the index (own instantiation, see WB)
   const bool ep_deleted = uni(ix.deleted[cur]) != 0;
   if (ix.kind == 0 && (bare || !ep_deleted)) c.n_dist++;  // hnswalg.h:347-351
   float tk[S];
@@ -1033,7 +1033,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
   }
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
-template <int METRIC, int S, int D16, bool WB = false>
+template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fa
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
       continue;
     }
-    const int rc = search_one_fast<METRIC, S, D16, WB>(ix, a, qi, smem);
+    const int rc = search_one_fast<METRIC, S, D16, WB, BARE>(ix, a, qi, smem);
     if (rc == 3 && threadIdx.x == 0) a.status[qi] = ST_HAZARD;
     wave_sync();
   }
@@ -1065,6 +1065,14 @@ hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t st
                                 : launch(strict_kernel<METRIC_IP>, ix, a, lds, stream);
 }
 
+// delete marks / filters: the variant with the reference's !bare_bone branches (runtime-dim and d=128 only)
+template <int METRIC, int D16>
+static hipError_t launch_fast_del(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
+  if (a.ef <= 64) return launch(fast_kernel<METRIC, 1, D16, false, false>, ix, a, lds, stream);
+  if (a.ef <= 128) return launch(fast_kernel<METRIC, 2, D16, false, false>, ix, a, lds, stream);
+  if (a.ef <= 256) return launch(fast_kernel<METRIC, 4, D16, false, false>, ix, a, lds, stream);
+  return launch(fast_kernel<METRIC, 8, D16, false, false>, ix, a, lds, stream);
+}
 template <int METRIC, int D16>
 static hipError_t launch_fast_md(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
   if (a.k == a.ef) {  // nothing is selected at the end: the variant that watches ties across the capacity boundary
@@ -1078,6 +1086,10 @@ static hipError_t launch_fast_md(const DevIndex &ix, const SearchArgs &a, size_t
 }
 hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
   const size_t lds = fast_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
+  if (ix.has_deleted) {
+    if (ix.metric == METRIC_L2) return ix.dim == 128 ? launch_fast_del<METRIC_L2, 8>(ix, a, lds, stream) : launch_fast_del<METRIC_L2, 0>(ix, a, lds, stream);
+    return launch_fast_del<METRIC_IP, 0>(ix, a, lds, stream);
+  }
   // compile-time dims for the common shapes (the runtime-dim kernel is 1.5-1.7x slower: measured on DEEP-10M, d=96)
   if (ix.metric == METRIC_L2) {
     switch (ix.dim) {
