@@ -391,7 +391,7 @@ hipError_t launch_slimq_prep(const DevSlimQ &sq, uint32_t dim, int metric, const
   return hipGetLastError();
 }
 
-template <int METRIC, int S, int NBLK>
+template <int METRIC, int S, int NBLK, bool DBG = false>
 __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
   const SlimQLds L = slimq_layout(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
@@ -560,7 +560,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   while (ps.cur != kNoRank) {
     const uint32_t node = pool_pop<S>(pval, ps, lane);
     const bool seen = set_has(tab, mask, node);
-    if (__builtin_expect(a.trace != nullptr, 0) && lane == 0 && n_tr + 1 < a.trace_cap) {
+    if (DBG && a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
       a.trace[(size_t)qi * a.trace_cap + n_tr] = node | (seen ? kChecked : 0u);
       a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = ps.size;
     }
@@ -586,7 +586,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         if (dj > ps.last) continue;                       // is_full(), :741
         pool_insert<S>(pkey, pval, ps, dj, cj, lane);      // :745
         n_ins++;
-        if (__builtin_expect(a.trace != nullptr, 0) && lane == 0 && n_tr + 1 < a.trace_cap) {
+        if (DBG && a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
           a.trace[(size_t)qi * a.trace_cap + n_tr] = cj | 0x40000000u;
           a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = __float_as_uint(dj);
         }
@@ -643,7 +643,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   return rc;
 }
 
-template <int METRIC, int S, int NBLK>
+template <int METRIC, int S, int NBLK, bool DBG = false>
 __global__ void __launch_bounds__(64) slimq_kernel(DevIndex ix, DevSlimQ sq, SlimQArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (a.select_mask != (1u << ST_TODO)) {
@@ -654,12 +654,12 @@ __global__ void __launch_bounds__(64) slimq_kernel(DevIndex ix, DevSlimQ sq, Sli
       while (m) {
         const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
         m &= m - 1;
-        slimq_one<METRIC, S, NBLK>(ix, sq, a, qi, smem);
+        slimq_one<METRIC, S, NBLK, DBG>(ix, sq, a, qi, smem);
       }
     }
     return;
   }
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) slimq_one<METRIC, S, NBLK>(ix, sq, a, qi, smem);   // first pass: every query
+  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) slimq_one<METRIC, S, NBLK, DBG>(ix, sq, a, qi, smem);   // first pass: every query
 }
 
 template <typename K>
@@ -682,6 +682,9 @@ static hipError_t launch_ms(const DevIndex &ix, const DevSlimQ &sq, const SlimQA
 }
 hipError_t launch_slimq(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, hipStream_t stream) {
   const size_t lds = slimq_lds_bytes(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
+  if (a.trace)   // the parity/debug entry: one generic configuration that records the SearchBuffer events
+    return ix.metric == METRIC_L2 ? launch_k(slimq_kernel<METRIC_L2, 16, 0, true>, ix, sq, a, lds, stream)
+                                  : launch_k(slimq_kernel<METRIC_IP, 16, 0, true>, ix, sq, a, lds, stream);
   if (ix.metric == METRIC_L2) {
     if (sq.padded == 128) return launch_ms<METRIC_L2, 2>(ix, sq, a, lds, stream);
     if (sq.padded == 768) return launch_ms<METRIC_L2, 12>(ix, sq, a, lds, stream);

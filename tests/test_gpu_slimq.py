@@ -149,6 +149,23 @@ def test_slimq_threshold_level_and_errors(env):
     assert e.value.status == P.HS_ERR_INVALID
 
 
+def test_slimq_event_trace_matches_oracle(env):
+    """The debug entry: every SearchBuffer pop and insert (with the estimated distance bits) in order."""
+    P, O, tmp = env
+    x = sift_like(3000 + 6, 128, seed=51, n_clusters=16)
+    base, q = x[:3000], x[3000:]
+    path = build(P, tmp, "trace", base, 0, 8)
+    ix = P.Index(path, P.HS_KIND_SLIMQ, 128)
+    ix.slimq_set_dataset(base)
+    ox = O.load_slimq(path)
+    for ef in (20, 150):
+        ix.set_ef(ef); ox.set(ef, ix.slimq_tconst(), base)
+        tr, _ = ix.slimq_trace(q, 10, 8192)
+        for i in range(q.shape[0]):
+            want = ox.trace(q[i], 10, 8192)
+            assert np.array_equal(tr[i][:len(want)], want) and np.all(tr[i][len(want):] == 0xFFFFFFFF)
+
+
 def test_slimq_cpp_facade(env):
     """A caller written against the reference's HierarchicalNSWSlimQ API (tests/facade_smoke.cpp, the call sequence
     of hnsw_slimq_strategy.h): per-query searchKnn(q, K, result) loop and searchKnnBatch."""

@@ -139,8 +139,8 @@ def test_hot_kernels_keep_their_wave_budget():
     want = {
         "_ZN2hs11fast_kernelILi0ELi1ELi8ELb0ELb1EEEvNS_8DevIndexENS_10SearchArgsE": 4,   # d=128 L2, ef <= 64
         "_ZN2hs11fast_kernelILi0ELi2ELi8ELb0ELb1EEEvNS_8DevIndexENS_10SearchArgsE": 4,   # d=128 L2, ef <= 128 (the bench point)
-        "_ZN2hs12slimq_kernelILi0ELi2ELi2EEEvNS_8DevIndexENS_8DevSlimQENS_9SlimQArgsE": 7,
-        "_ZN2hs12slimq_kernelILi0ELi4ELi2EEEvNS_8DevIndexENS_8DevSlimQENS_9SlimQArgsE": 6,
+        "_ZN2hs12slimq_kernelILi0ELi2ELi2ELb0EEEvNS_8DevIndexENS_8DevSlimQENS_9SlimQArgsE": 7,
+        "_ZN2hs12slimq_kernelILi0ELi4ELi2ELb0EEEvNS_8DevIndexENS_8DevSlimQENS_9SlimQArgsE": 6,
         "_ZN2hs14bf_scan_kernelILi0EEEvPKfPKmjjS2_jjjPNS_7BfEntryE": 5,
     }
     for name, waves in want.items():
