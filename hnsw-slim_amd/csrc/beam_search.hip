@@ -206,11 +206,14 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
                                             uint32_t cnt, int lane, Hook between = Hook()) {
   const int sub = lane & 3, grp = lane >> 2;
   float out = FLT_MAX;
-  if (D16 == 0 && METRIC == METRIC_L2 && (ix.dim & 15u)) {
-    // dim % 16 != 0: the reference's SIMD4 / residual recipes (dist_recipe.hpp l2_general), one lane per row
+  if (D16 == 0 && (ix.dim & 15u)) {
+    // dim % 16 != 0: the reference's SIMD4 / residual recipes (dist_recipe.hpp l2_general / ip_general), one lane per row
     for (uint32_t base = 0; base < cnt; base += 64) {
       const uint32_t j = base + lane;
-      if (j < cnt) nd[j] = l2_general(qv, ix.vec + (size_t)nid[j] * ix.dim, ix.dim);
+      if (j < cnt) {
+        const float *row = ix.vec + (size_t)nid[j] * ix.dim;
+        nd[j] = METRIC == METRIC_L2 ? l2_general(qv, row, ix.dim) : ip_general(qv, row, ix.dim);
+      }
       if (base == 0) between();
     }
     return out;

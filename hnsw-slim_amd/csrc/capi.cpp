@@ -344,8 +344,6 @@ hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size
   if (!path || !out) return fail(HS_ERR_INVALID, "null argument");
   if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
   if (dim == 0) return fail(HS_ERR_INVALID, "dim must be > 0");
-  if (metric == HS_METRIC_IP && dim % 16 != 0)
-    return fail(HS_ERR_UNSUPPORTED, "inner product with dim % 16 != 0 is not supported (SIMD16 recipe only)");
   if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
   PackedIndex p;
   try {

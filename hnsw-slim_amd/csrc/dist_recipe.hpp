@@ -130,9 +130,91 @@ HS_HD float l2_general(const float *q, const float *x, uint32_t d) {
   }
   return l2_scalar(q, x, d);
 }
+// InnerProductSpace's dispatch for every dim (space_ip.h:374-382) on an AVX-512 host: dim%16==0 -> SIMD16ExtAVX512
+// (ip_row16 above: FMA accumulators + halves tree); dim%4==0 -> SIMD4ExtAVX (:24-69: eight lane accumulators over the
+// 16-element steps as multiply-then-add, folded lo+hi to four, 4-element steps added to those, TmpRes[0..3] summed left to
+// right); dim>16 -> SIMD16 on the first dim/16*16 elements + scalar InnerProduct on the rest, 1-(res+tail) (:311-322);
+// dim>4 -> SIMD4 + scalar rest (:324-337); else scalar (:6-19).  One accumulator chain at a time (the chains are
+// independent, so the values are those of the vector code) -- small register footprint on the device.
+HS_HD float ip_quad16(const float *q, const float *x, uint32_t d16, uint32_t j) {  // (a_j+a_{j+8}) + (a_{j+4}+a_{j+12})
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;  // lane accumulators j, j+4, j+8, j+12 of the SIMD16 loop (FMA)
+#pragma unroll 1
+  for (uint32_t s = 0; s < d16; s += 16) {
+    v0 = __builtin_fmaf(q[s + j], x[s + j], v0);
+    v1 = __builtin_fmaf(q[s + j + 4], x[s + j + 4], v1);
+    v2 = __builtin_fmaf(q[s + j + 8], x[s + j + 8], v2);
+    v3 = __builtin_fmaf(q[s + j + 12], x[s + j + 12], v3);
+  }
+  const float lo = v0 + v2;
+  const float hi = v1 + v3;
+  return lo + hi;
+}
+HS_HD float ip_part16(const float *q, const float *x, uint32_t d16) {  // _mm512_reduce_add_ps order
+  float e = 0.f, o = 0.f;
+#pragma unroll 1
+  for (uint32_t j = 0; j < 2; j++) {
+    const float a = ip_quad16(q, x, d16, j);
+    const float b = ip_quad16(q, x, d16, j + 2);
+    const float h = a + b;   // h4[j] + h4[j+2]
+    if (j == 0) e = h; else o = h;
+  }
+  return e + o;
+}
+HS_HD float ip_part4(const float *q, const float *x, uint32_t d4) {  // InnerProductSIMD4ExtAVX, d4 % 4 == 0
+  const uint32_t d16 = d4 & ~15u;
+  float sum = 0.f;
+#pragma unroll 1
+  for (uint32_t j = 0; j < 4; j++) {
+    float lo = 0.f, hi = 0.f;  // ymm lanes j and j+4
+#pragma unroll 1
+    for (uint32_t s = 0; s < d16; s += 16) {
+      float p = q[s + j] * x[s + j];
+      lo = lo + p;
+      p = q[s + 8 + j] * x[s + 8 + j];
+      lo = lo + p;
+      p = q[s + 4 + j] * x[s + 4 + j];
+      hi = hi + p;
+      p = q[s + 12 + j] * x[s + 12 + j];
+      hi = hi + p;
+    }
+    float a = lo + hi;
+#pragma unroll 1
+    for (uint32_t s = d16; s < d4; s += 4) {
+      const float p = q[s + j] * x[s + j];
+      a = a + p;
+    }
+    sum = j == 0 ? a : sum + a;   // ((sp0 + sp1) + sp2) + sp3
+  }
+  return sum;
+}
+HS_HD float ip_scalar(const float *q, const float *x, uint32_t d) {
+  float r = 0.f;
+  for (uint32_t i = 0; i < d; i++) {
+    const float p = q[i] * x[i];
+    r = r + p;
+  }
+  return r;
+}
+HS_HD float ip_general(const float *q, const float *x, uint32_t d) {  // the distance: 1 - <q,x>
+  if ((d & 15u) == 0) return 1.0f - ip_part16(q, x, d);
+  if ((d & 3u) == 0) return 1.0f - ip_part4(q, x, d);
+  if (d > 16) {
+    const uint32_t d16 = d & ~15u;
+    const float r = ip_part16(q, x, d16);
+    const float t = ip_scalar(q + d16, x + d16, d - d16);
+    return 1.0f - (r + t);
+  }
+  if (d > 4) {
+    const uint32_t d4 = d & ~3u;
+    const float r = ip_part4(q, x, d4);
+    const float t = ip_scalar(q + d4, x + d4, d - d4);
+    return 1.0f - (r + t);
+  }
+  return 1.0f - ip_scalar(q, x, d);
+}
 inline float host_dist(Metric m, const float *q, const float *x, size_t d) {
   if (m == METRIC_L2) return (d & 15) ? l2_general(q, x, (uint32_t)d) : l2_row16(q, x, d);
-  return ip_row16(q, x, d);   // callers guarantee dim % 16 == 0 for the inner product
+  return (d & 15) ? ip_general(q, x, (uint32_t)d) : ip_row16(q, x, d);
 }
 
 }  // namespace hs

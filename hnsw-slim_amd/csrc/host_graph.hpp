@@ -78,7 +78,6 @@ struct VanillaGraph {
   std::mutex global;
 
   void init(size_t n, size_t d, Metric m, size_t M_, size_t efC_, const std::string &bf) {
-    if (m == METRIC_IP && d % 16) throw std::runtime_error("inner product supports dim % 16 == 0 only");
     max_elements = n; dim = d; metric = m;
     M = M_ > 10000 ? 10000 : M_;           // hnswalg.h:97-107
     maxM = M; maxM0 = 2 * M;

@@ -504,8 +504,11 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   auto flush = [&]() {  // exact distances of the pending expansions, then the k-bounded heap, in expansion order
     wave_sync();
     const int sub = lane & 3, grp = lane >> 2;
-    if (METRIC == METRIC_L2 && (ix.dim & 15u)) {  // the reference's SIMD4 / residual recipes, one lane per row
-      if ((uint32_t)lane < n_pend) pd[lane] = l2_general(qv, sq.raw + (size_t)pend[lane] * ix.dim, ix.dim);
+    if (ix.dim & 15u) {  // the reference's SIMD4 / residual recipes, one lane per row
+      if ((uint32_t)lane < n_pend) {
+        const float *row = sq.raw + (size_t)pend[lane] * ix.dim;
+        pd[lane] = METRIC == METRIC_L2 ? l2_general(qv, row, ix.dim) : ip_general(qv, row, ix.dim);
+      }
     } else {
     const bool act = (uint32_t)grp < n_pend;
     const uint32_t id = pend[act ? grp : 0];

@@ -70,12 +70,10 @@ class L2Space : public SpaceInterface<float> {
 class InnerProductSpace : public SpaceInterface<float> {
   size_t data_size_, dim_;
   static float fn(const void *a, const void *b, const void *p) {
-    return hs::ip_row16((const float *)a, (const float *)b, *(const size_t *)p);
+    return hs::host_dist(hs::METRIC_IP, (const float *)a, (const float *)b, *(const size_t *)p);  // every dim
   }
  public:
-  explicit InnerProductSpace(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {
-    if (dim % 16) throw std::runtime_error("hnswlib_amd: inner product with dim % 16 != 0 is not supported yet");
-  }
+  explicit InnerProductSpace(size_t dim) : data_size_(dim * sizeof(float)), dim_(dim) {}
   size_t get_data_size() override { return data_size_; }
   DISTFUNC<float> get_dist_func() override { return fn; }
   void *get_dist_func_param() override { return &dim_; }

@@ -29,7 +29,7 @@ typedef enum {
   HS_ERR_CORRUPT = 2,     /* "Index seems to be corrupted or unsupported" hnswalg.h:823-836 */
   HS_ERR_NOMEM = 3,       /* "Not enough memory: ..."                   hnswalg_slim.h:785-788 */
   HS_ERR_INVALID = 4,     /* bad argument                                */
-  HS_ERR_UNSUPPORTED = 5, /* e.g. inner product with dim % 16 != 0        */
+  HS_ERR_UNSUPPORTED = 5, /* e.g. SlimQ with dim < 64, brute force k > 64  */
   HS_ERR_DEVICE = 6,      /* HIP runtime error / no device               */
   HS_ERR_CAPACITY = 7     /* a query outgrew even the fallback on-chip scratch */
 } hs_status;
@@ -65,7 +65,7 @@ int hs_device_count(void);
 /* loadIndex(path, space, max_elements): hnswalg.h:781-893 (HS_KIND_HNSW), hnswalg_slim.h:753-815
  * (HS_KIND_SLIM), hnswalg_slimq.h:1218-1313 (HS_KIND_SLIMQ).  Parses the reference's serialized index, repacks it
  * (row-major vectors + CSR adjacency + fixed-stride tiles; RaBitQ records for SlimQ) and uploads it to HIP device
- * `device`.  ef starts at 10 as in the reference.  L2 takes every dim; the inner product needs dim % 16 == 0. */
+ * `device`.  ef starts at 10 as in the reference.  Both metrics take every dim. */
 hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements,
                         int device, hs_index **out);
 void hs_index_free(hs_index *ix);                        /* ~HierarchicalNSW* / clear(): hnswalg_slim.h:154-167 */

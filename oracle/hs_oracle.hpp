@@ -111,10 +111,53 @@ inline float ip_simd16(const float *a, const float *b, size_t d) {
   for (int j = 0; j < 2; j++) h2[j] = h4[j] + h4[j + 2];
   return h2[0] + h2[1];
 }
+// space_ip.h:24-69 InnerProductSIMD4ExtAVX (the SIMD4 entry on an AVX host): one ymm accumulator takes two 8-wide
+// multiply-then-add steps per 16 elements (:41-53), its halves are added (:56), 4-wide steps follow (:58-64), and the
+// four lanes are summed left to right (:67).
+inline float ip_simd4(const float *a, const float *b, size_t d) {
+  float y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t n16 = d >> 4, n4 = d >> 2, i = 0;
+  for (size_t s = 0; s < n16; s++)
+    for (int h = 0; h < 2; h++, i += 8)
+      for (int j = 0; j < 8; j++) {
+        float p = a[i + j] * b[i + j];
+        y[j] = y[j] + p;
+      }
+  float x4[4];
+  for (int j = 0; j < 4; j++) x4[j] = y[j] + y[j + 4];
+  for (; i < n4 * 4; i += 4)
+    for (int j = 0; j < 4; j++) {
+      float p = a[i + j] * b[i + j];
+      x4[j] = x4[j] + p;
+    }
+  return ((x4[0] + x4[1]) + x4[2]) + x4[3];
+}
+// space_ip.h:6-14 scalar InnerProduct.
+inline float ip_scalar(const float *a, const float *b, size_t d) {
+  float r = 0;
+  for (size_t i = 0; i < d; i++) {
+    float p = a[i] * b[i];
+    r = r + p;
+  }
+  return r;
+}
+// space_ip.h:374-382 dispatch; residual forms :311-337 return 1 - (res + res_tail).
 inline float ip_dist(const float *a, const float *b, size_t d) {
-  if (d % 16 != 0) throw std::runtime_error("oracle: IP restated for dim%16==0 only");
-  float ip = ip_simd16(a, b, d);
-  return 1.0f - ip;
+  if (d % 16 == 0) return 1.0f - ip_simd16(a, b, d);
+  if (d % 4 == 0) return 1.0f - ip_simd4(a, b, d);
+  if (d > 16) {
+    size_t d16 = d >> 4 << 4;
+    float r = ip_simd16(a, b, d16);
+    float t = ip_scalar(a + d16, b + d16, d - d16);
+    return 1.0f - (r + t);
+  }
+  if (d > 4) {
+    size_t d4 = d >> 2 << 2;
+    float r = ip_simd4(a, b, d4);
+    float t = ip_scalar(a + d4, b + d4, d - d4);
+    return 1.0f - (r + t);
+  }
+  return 1.0f - ip_scalar(a, b, d);
 }
 inline float dist(Metric m, const float *a, const float *b, size_t d) {
   return m == METRIC_L2 ? l2_dist(a, b, d) : ip_dist(a, b, d);

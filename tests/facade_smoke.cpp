@@ -43,10 +43,11 @@ int main(int argc, char **argv) {
     } catch (std::runtime_error &e) {
       ok += std::string(e.what()) == "HierarchicalNSWSlim does not support addPoint";
     }
-    try {
-      hnswlib::InnerProductSpace bad(30);
-    } catch (std::runtime_error &) {
-      ok++;
+    {
+      hnswlib::InnerProductSpace ip7(7);  // every dim, as in the reference (space_ip.h:374-382): 1 - sum i*2i, i<7
+      float u[7], v[7];
+      for (int i = 0; i < 7; i++) { u[i] = i; v[i] = 2 * i; }
+      ok += ip7.get_dist_func()(u, v, ip7.get_dist_func_param()) == 1.0f - 182.0f;
     }
     float a[16], b[16];
     for (int i = 0; i < 16; i++) { a[i] = i; b[i] = 2 * i; }

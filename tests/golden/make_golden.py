@@ -43,6 +43,24 @@ def dist_fixture(tmp):
     np.savez_compressed(os.path.join(GOLDEN, "dist_ref.npz"), **out)
 
 
+def ip_odd_dims_fixture(tmp):
+    """InnerProductSpace off the SIMD16 path (space_ip.h:374-382): scalar (1-3), SIMD4ExtAVX (4, 20, 100), SIMD4 residuals
+    (7, 13), SIMD16 residuals (23, 70, 133).  Kept in its own file so that dist_ref.npz stays byte-stable."""
+    out = {}
+    rng = np.random.default_rng(20250202)
+    for d in (1, 3, 4, 7, 13, 20, 23, 70, 100, 133):
+        a = (rng.standard_normal((64, d)) * 3).astype(np.float32)
+        b = (rng.standard_normal((64, d)) * 3).astype(np.float32)
+        fa, fb, fo = (os.path.join(tmp, f"{x}.bin") for x in "abo")
+        write_fvecs(fa, a)
+        write_fvecs(fb, b)
+        run("dist", "ip", fa, fb, fo)
+        out[f"ip_{d}_a"] = a
+        out[f"ip_{d}_b"] = b
+        out[f"ip_{d}_ref"] = np.fromfile(fo, np.float32)
+    np.savez_compressed(os.path.join(GOLDEN, "dist_ref_ip_odd.npz"), **out)
+
+
 def index_fixture(tmp, name, metric, base, queries, M, efC, efs, k=10):
     fb, fq = os.path.join(tmp, "b.fvecs"), os.path.join(tmp, "q.fvecs")
     write_fvecs(fb, base)
@@ -151,6 +169,14 @@ def main():
         for d, seed in ((20, 11), (21, 13), (10, 15)):
             index_fixture(tmp, f"l2_cont_d{d}", "l2", mixture(600, d, seed), mixture(40, d, seed + 1), 8, 60, [10, 32])
         rabitq_fixture(tmp)
+        # inner product off the SIMD16 path: SIMD4ExtAVX (d=20), SIMD16ExtResiduals (d=21), SIMD4ExtResiduals (d=10)
+        ip_odd_dims_fixture(tmp)
+        for d, seed in ((20, 21), (21, 23), (10, 25)):
+            b = mixture(600, d, seed, lo=-1, hi=1, sigma=0.5)
+            q = mixture(40, d, seed + 1, lo=-1, hi=1, sigma=0.5)
+            b /= np.linalg.norm(b, axis=1, keepdims=True)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            index_fixture(tmp, f"ip_d{d}", "ip", b.astype(np.float32), q.astype(np.float32), 8, 60, [10, 32])
     print("golden fixtures written to", GOLDEN)
 
 

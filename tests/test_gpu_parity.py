@@ -34,7 +34,8 @@ def _pq_sorted(d, l, c):
 
 
 @pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48),
-                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10)])
+                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10),
+                                             ("ip_d20", IP, 20), ("ip_d21", IP, 21), ("ip_d10", IP, 10)])
 def test_vanilla_vs_compiled_reference(hs, oracle, name, metric, dim):
     g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     path = os.path.join(GOLDEN, f"{name}.hnsw.bin")
@@ -184,6 +185,17 @@ def test_slim_dims_off_the_simd16_path(hs, oracle, tmp_path, dim):
     base = mixture(6000, dim, 61, integer=True)
     q = mixture(100, dim, 62, integer=True)
     _slim_case(hs, oracle, tmp_path, base, q, dim, L2, 16, 100, [32, 100])
+
+
+@pytest.mark.parametrize("dim", (100, 70, 7, 3))
+def test_slim_inner_product_off_the_simd16_path(hs, oracle, tmp_path, dim):
+    """InnerProductSpace with dim % 16 != 0 (space_ip.h:374-382): SIMD4ExtAVX (100), SIMD16 + scalar rest (70), SIMD4 +
+    scalar rest (7), scalar (3) -- strict and fast kernels, unit-norm rows."""
+    base = mixture(5000, dim, 63, lo=-1, hi=1, sigma=0.5)
+    q = mixture(100, dim, 64, lo=-1, hi=1, sigma=0.5)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _slim_case(hs, oracle, tmp_path, base.astype(np.float32), q.astype(np.float32), dim, IP, 16, 100, [32, 100])
 
 
 def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):

@@ -109,6 +109,17 @@ def test_slimq_d100_residual_recipes(env):
     check(P, O, path, base, q, 0, 10, (40, 120))
 
 
+def test_slimq_d100_ip_residual_recipes(env):
+    """Inner product at dim 100: estimator on the padded 128-bit codes, exact re-rank through InnerProductSIMD4ExtAVX."""
+    P, O, tmp = env
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal((3000 + 100, 100)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    base, q = x[:3000], x[3000:]
+    path = build(P, tmp, "d100ip", base, 1, 4)
+    check(P, O, path, base, q, 1, 10, (40, 120), t_const=31.0)
+
+
 def test_slimq_d768_ip(env):
     P, O, tmp = env
     rng = np.random.default_rng(9)

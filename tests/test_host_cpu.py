@@ -39,7 +39,8 @@ def test_heap_emulation_matches_libstdcxx(hs):
 
 
 @pytest.mark.parametrize("name,metric", [("l2_cont_d32", L2), ("l2_int_d16", L2), ("ip_d48", IP), ("l2_cont_d20", L2),
-                                         ("l2_cont_d21", L2), ("l2_cont_d10", L2)])
+                                         ("l2_cont_d21", L2), ("l2_cont_d10", L2), ("ip_d20", IP), ("ip_d21", IP),
+                                         ("ip_d10", IP)])
 def test_serial_builder_writes_reference_bytes(hs, tmp_path, name, metric):
     """threads=1 build == the reference's serial addPoint loop + saveIndex, byte for byte."""
     g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
@@ -103,8 +104,8 @@ def test_slim_convert_roundtrip(hs, oracle, tmp_path):
 
 
 def test_error_conventions(hs, tmp_path):
-    with pytest.raises(hs.HsError, match="dim % 16"):
-        hs.Index(str(tmp_path / "x"), hs.HS_KIND_SLIM, 30, hs.HS_METRIC_IP)
+    with pytest.raises(hs.HsError, match="dim must be > 0"):
+        hs.Index(str(tmp_path / "x"), hs.HS_KIND_SLIM, 0, hs.HS_METRIC_IP)
     if hs.device_count() == 0:
         with pytest.raises(hs.HsError) as e:
             hs.Index(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), hs.HS_KIND_HNSW, 32)

@@ -11,23 +11,23 @@ L2, IP = 0, 1
 
 
 def test_distance_recipes_bit_exact(oracle):
-    g = np.load(os.path.join(GOLDEN, "dist_ref.npz"))
     checked = 0
-    for key in g.files:
-        if not key.endswith("_ref"):
-            continue
-        metric, d = key.split("_")[:2]
-        if metric == "ip" and int(d) % 16:
-            continue
-        a, b, ref = g[f"{metric}_{d}_a"], g[f"{metric}_{d}_b"], g[key]
-        got = oracle.dist(L2 if metric == "l2" else IP, a, b)
-        assert got.tobytes() == ref.tobytes(), f"{metric} d={d}: restated recipe differs from the reference"
-        checked += 1
-    assert checked >= 14
+    for fname in ("dist_ref.npz", "dist_ref_ip_odd.npz"):
+        g = np.load(os.path.join(GOLDEN, fname))
+        for key in g.files:
+            if not key.endswith("_ref"):
+                continue
+            metric, d = key.split("_")[:2]
+            a, b, ref = g[f"{metric}_{d}_a"], g[f"{metric}_{d}_b"], g[key]
+            got = oracle.dist(L2 if metric == "l2" else IP, a, b)
+            assert got.tobytes() == ref.tobytes(), f"{metric} d={d}: restated recipe differs from the reference"
+            checked += 1
+    assert checked >= 25
 
 
 @pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48),
-                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10)])
+                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10),
+                                             ("ip_d20", IP, 20), ("ip_d21", IP, 21), ("ip_d10", IP, 10)])
 def test_vanilla_search_matches_reference(oracle, name, metric, dim):
     g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     ix = oracle.load(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "hnsw", metric, dim)
