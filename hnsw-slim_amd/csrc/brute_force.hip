@@ -28,6 +28,40 @@ struct BfEntry { float d; uint32_t row; uint64_t label; };   // 16 bytes
 
 __device__ __forceinline__ bool bf_less(float d, uint64_t l, const BfEntry &e) { return d < e.d || (d == e.d && l < e.label); }
 
+// Candidates of one pass (mask m, value d in the owning lane, row = rb + (lane >> SHIFT)) against one query's sorted k-list.
+template <int SHIFT>
+__device__ __forceinline__ void bf_offer(unsigned long long m, float d, uint32_t rb, const uint64_t *labels, BfEntry *L, uint32_t *sz,
+                                         uint32_t k, int lane) {
+  while (m) {
+    const int l = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
+    const uint32_t rj = rb + (uint32_t)(l >> SHIFT);
+    if (lane == 0) {
+      const uint64_t lab = labels ? labels[rj] : (uint64_t)rj;
+      uint32_t cur = *sz;
+      if (cur < k || bf_less(dj, lab, L[k - 1])) {
+        uint32_t pos = cur < k ? cur : k - 1;
+        while (pos > 0 && bf_less(dj, lab, L[pos - 1])) { L[pos] = L[pos - 1]; pos--; }
+        L[pos] = BfEntry{dj, rj, lab};
+        if (cur < k) *sz = cur + 1;
+      }
+    }
+    wave_sync();
+  }
+}
+
+// Sorted runs of this (chunk, wave), padded with +inf, for the merge kernel.
+__device__ __forceinline__ void bf_write_runs(const BfEntry *mine, const uint32_t *msz, BfEntry *partial, uint32_t q0, uint32_t nq, uint32_t k,
+                                              int wave, int lane) {
+  const uint32_t run = blockIdx.x * kWaves + wave, nruns = gridDim.x * kWaves;
+  for (int t = 0; t < kQT; t++) {
+    if (q0 + t >= nq) break;
+    BfEntry *dst = partial + ((size_t)(q0 + t) * nruns + run) * k;
+    for (uint32_t i = lane; i < k; i += 64) dst[i] = i < msz[t] ? mine[(size_t)t * k + i] : BfEntry{FLT_MAX, 0xFFFFFFFFu, ~0ull};
+  }
+}
+
 template <int METRIC>
 __global__ void __launch_bounds__(64 * kWaves) bf_scan_kernel(const float *base, const uint64_t *labels, uint32_t n, uint32_t dim,
                                                             const float *queries, uint32_t nq, uint32_t k, uint32_t rows_per_block,
@@ -72,35 +106,50 @@ __global__ void __launch_bounds__(64 * kWaves) bf_scan_kernel(const float *base,
       if (q0 + t >= nq) continue;
       const uint32_t sz = msz[t];
       const float thr = sz < k ? FLT_MAX : mine[(size_t)t * k + k - 1].d;
-      unsigned long long m = __ballot(act && owner && d <= thr);   // bruteforce.h:120 `dist <= lastdist`
-      while (m) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
-        const uint32_t rj = rb + (uint32_t)(l >> 2);
-        if (lane == 0) {
-          const uint64_t lab = labels ? labels[rj] : (uint64_t)rj;
-          BfEntry *L = mine + (size_t)t * k;
-          uint32_t cur = msz[t];
-          if (cur < k || bf_less(dj, lab, L[k - 1])) {
-            uint32_t pos = cur < k ? cur : k - 1;
-            while (pos > 0 && bf_less(dj, lab, L[pos - 1])) { L[pos] = L[pos - 1]; pos--; }
-            L[pos] = BfEntry{dj, rj, lab};
-            if (cur < k) msz[t] = cur + 1;
-          }
-        }
-        wave_sync();
-      }
+      bf_offer<2>(__ballot(act && owner && d <= thr), d, rb, labels, mine + (size_t)t * k, msz + t, k, lane);   // bruteforce.h:120 `dist <= lastdist`
     }
   }
   wave_sync();
-  // per-(chunk, wave) sorted runs, padded with +inf
-  const uint32_t run = blockIdx.x * kWaves + wave, nruns = gridDim.x * kWaves;
-  for (int t = 0; t < kQT; t++) {
-    if (q0 + t >= nq) break;
-    BfEntry *dst = partial + ((size_t)(q0 + t) * nruns + run) * k;
-    for (uint32_t i = lane; i < k; i += 64) dst[i] = i < msz[t] ? mine[(size_t)t * k + i] : BfEntry{FLT_MAX, 0xFFFFFFFFu, ~0ull};
+  bf_write_runs(mine, msz, partial, q0, nq, k, wave, lane);
+}
+
+// dim % 16 != 0: the reference's SIMD4 / residual / scalar recipes (dist_recipe.hpp l2_general / ip_general), one lane per
+// row and 64 rows per wave and pass -- the shapes ground truth is occasionally needed for (GloVe d=100, 25, 50, ...), far
+// from the tuned kernel above but the same values.
+template <int METRIC>
+__global__ void __launch_bounds__(64 * kWaves) bf_scan_general_kernel(const float *base, const uint64_t *labels, uint32_t n, uint32_t dim,
+                                                                    const float *queries, uint32_t nq, uint32_t k,
+                                                                    uint32_t rows_per_block, BfEntry *partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *q = reinterpret_cast<float *>(smem);                                                      // kQT x dim
+  BfEntry *lists = reinterpret_cast<BfEntry *>(smem + (((size_t)kQT * dim * 4 + 15) & ~(size_t)15));   // kWaves x kQT x k
+  uint32_t *sizes = reinterpret_cast<uint32_t *>(lists + (size_t)kWaves * kQT * k);               // kWaves x kQT
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t q0 = blockIdx.y * kQT;
+  for (uint32_t i = tid; i < kQT * dim; i += 64 * kWaves) {
+    const uint32_t t = i / dim;
+    q[i] = q0 + t < nq ? queries[(size_t)(q0 + t) * dim + (i - t * dim)] : 0.f;
   }
+  if (tid < kWaves * kQT) sizes[tid] = 0;
+  __syncthreads();
+  BfEntry *mine = lists + (size_t)wave * kQT * k;
+  uint32_t *msz = sizes + wave * kQT;
+  const uint32_t r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  for (uint32_t rb = r0 + wave * 64; rb < r1; rb += 64 * kWaves) {
+    const uint32_t row = rb + lane;
+    const bool act = row < r1;
+    const float *x = base + (size_t)(act ? row : r0) * dim;
+#pragma unroll 1
+    for (int t = 0; t < kQT; t++) {
+      if (q0 + t >= nq) break;
+      const float d = METRIC == METRIC_L2 ? l2_general(q + (size_t)t * dim, x, dim) : ip_general(q + (size_t)t * dim, x, dim);
+      const uint32_t sz = msz[t];
+      const float thr = sz < k ? FLT_MAX : mine[(size_t)t * k + k - 1].d;
+      bf_offer<0>(__ballot(act && d <= thr), d, rb, labels, mine + (size_t)t * k, msz + t, k, lane);
+    }
+  }
+  wave_sync();
+  bf_write_runs(mine, msz, partial, q0, nq, k, wave, lane);
 }
 
 // one wave per query: k rounds of a k-way merge over the sorted runs
@@ -167,9 +216,11 @@ size_t bf_partial_bytes(uint32_t n, uint32_t nq, uint32_t k, uint32_t *grid_x, u
 hipError_t launch_brute_force(const float *base, const uint64_t *labels, uint32_t n, uint32_t dim, int metric, const float *queries,
                               uint32_t nq, uint32_t k, void *partial, uint32_t grid_x, uint32_t rows_per_block, uint64_t *out_labels,
                               float *out_dists, uint32_t *out_counts, hipStream_t stream) {
-  const size_t lds = (size_t)kQT * dim * 4 + (size_t)kWaves * kQT * k * sizeof(BfEntry) + kWaves * kQT * 4;
+  const size_t lds = (((size_t)kQT * dim * 4 + 15) & ~(size_t)15) + (size_t)kWaves * kQT * k * sizeof(BfEntry) + kWaves * kQT * 4;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;   // dim above ~4500: the query tile no longer fits the CU's LDS
   const dim3 grid(grid_x, (nq + kQT - 1) / kQT);
-  auto kern = metric == METRIC_L2 ? bf_scan_kernel<METRIC_L2> : bf_scan_kernel<METRIC_IP>;
+  auto kern = (dim & 15u) ? (metric == METRIC_L2 ? bf_scan_general_kernel<METRIC_L2> : bf_scan_general_kernel<METRIC_IP>)
+                          : (metric == METRIC_L2 ? bf_scan_kernel<METRIC_L2> : bf_scan_kernel<METRIC_IP>);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -788,7 +788,8 @@ hs_status hs_brute_force_dev(const float *d_base, const uint64_t *d_labels, size
                              uint32_t *d_out_counts, void *stream_) {
   if (!d_base || !d_queries || !d_out_labels || !d_out_dists) return fail(HS_ERR_INVALID, "null argument");
   if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
-  if (dim == 0 || dim % 16 != 0) return fail(HS_ERR_UNSUPPORTED, "brute force supports dim % 16 == 0 only");
+  if (dim == 0) return fail(HS_ERR_INVALID, "dim must be > 0");
+  if (dim > 4096) return fail(HS_ERR_UNSUPPORTED, "brute force supports dim <= 4096");
   if (k == 0 || k > 64) return fail(HS_ERR_UNSUPPORTED, "brute force supports 1 <= k <= 64");
   if (n > 0xFFFFFFF0u || nq > 0x7FFFFFFFu) return fail(HS_ERR_INVALID, "too many rows / queries");
   if (nq == 0) return HS_OK;

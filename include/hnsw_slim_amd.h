@@ -154,7 +154,7 @@ hs_status hs_slimq_trace(hs_index *ix, const float *queries, size_t nq, size_t k
 /* ---- exhaustive k-NN (ground truth): hnswlib::BruteforceSearch::searchKnn, bruteforce.h:106-135, for a batch ------
  * Result per query: the k lexicographically smallest (dist, label) pairs -- what the reference's priority_queue of
  * pairs ends up holding whatever the scan order -- sorted ascending; distances by the same fp32 recipes as the
- * graph search.  labels NULL = row index.  dim % 16 == 0, k <= 64.  out_counts[q] = min(k, n). */
+ * graph search.  labels NULL = row index.  dim <= 4096 (dim % 16 == 0 is the tuned kernel), k <= 64.  out_counts[q] = min(k, n). */
 hs_status hs_brute_force(const float *base, size_t n, size_t dim, int metric, const uint64_t *labels, const float *queries,
                          size_t nq, size_t k, int device, uint64_t *out_labels, float *out_dists, uint32_t *out_counts);
 /* device pointers; synchronises `stream` before returning */

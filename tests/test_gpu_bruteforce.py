@@ -26,7 +26,10 @@ def _expect(O, metric, base, q, k, labels=None):
 
 
 @pytest.mark.parametrize("n,d,nq,k,metric,integer", [(5000, 128, 37, 10, 0, True), (777, 32, 9, 1, 0, False), (3000, 96, 20, 64, 0, True),
-                                                     (2500, 48, 16, 10, 1, False), (40, 16, 5, 10, 0, True), (9, 16, 3, 10, 0, False)])
+                                                     (2500, 48, 16, 10, 1, False), (40, 16, 5, 10, 0, True), (9, 16, 3, 10, 0, False),
+                                                     # dim % 16 != 0: one lane per row, the SIMD4 / residual / scalar recipes
+                                                     (3000, 100, 21, 10, 0, True), (1500, 70, 9, 10, 0, False), (900, 7, 9, 64, 0, True),
+                                                     (2000, 100, 12, 10, 1, False), (800, 21, 5, 3, 1, False), (300, 3, 4, 10, 1, False)])
 def test_brute_force_matches_reference_semantics(env, n, d, nq, k, metric, integer):
     P, O = env
     if integer:   # tiny value range: many exactly equal distances -> the label tie-break decides
@@ -58,7 +61,7 @@ def test_brute_force_custom_labels_break_ties(env):
 
 def test_brute_force_errors(env):
     P, _ = env
-    base, q = mixture(100, 20, 1), mixture(3, 20, 2)
+    base, q = mixture(10, 4112, 1), mixture(3, 4112, 2)
     with pytest.raises(P.HsError) as e:
         P.brute_force(base, q, 5)
     assert e.value.status == P.HS_ERR_UNSUPPORTED
