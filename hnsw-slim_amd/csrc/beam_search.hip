@@ -194,8 +194,9 @@ __device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
 }
 
 // Distances query -> rows nid[0..cnt), 16 rows per pass, 4 lanes per row; nd[j] receives the value.
-// D16 = dim/16 when known at compile time (d=128 -> 8: eight 16-byte loads per lane, fully unrolled), 0 =
-// runtime dim.  `between()` runs after the first pass's row loads have been ISSUED and before they are
+// D16 = dim/16 when known at compile time (d=128 -> 8: eight 16-byte loads per lane, fully unrolled), 0 = runtime dim
+// with dim % 16 == 0, -1 = any runtime dim (adds the recipes for dim % 16 != 0; those instantiations carry their cost).
+// `between()` runs after the first pass's row loads have been ISSUED and before they are
 // consumed: LDS-only work placed there (the candidate heap's pop) hides under the HBM latency.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
@@ -206,8 +207,19 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
                                             uint32_t cnt, int lane, Hook between = Hook()) {
   const int sub = lane & 3, grp = lane >> 2;
   float out = FLT_MAX;
-  if (D16 == 0 && (ix.dim & 15u)) {
-    // dim % 16 != 0: the reference's SIMD4 / residual recipes (dist_recipe.hpp l2_general / ip_general), one lane per row
+  if (D16 < 0 && (ix.dim & 15u) && !(ix.dim & 3u)) {
+    // dim % 4 == 0: the reference's 4-lane recipes, 4 lanes per row and 16 rows per pass (wave_util.hpp quad_dist4)
+    for (uint32_t base = 0; base < cnt; base += 16) {
+      const uint32_t j = base + grp;
+      const bool act = j < cnt;
+      const uint32_t id = nid[act ? j : 0];
+      const float r = quad_dist4<METRIC>(qv + sub, ix.vec + (size_t)id * ix.dim + sub, ix.dim, [&]() { if (base == 0) between(); });
+      if (act && sub == 0) nd[j] = r;
+    }
+    return out;
+  }
+  if (D16 < 0 && (ix.dim & 15u)) {
+    // other dims: the reference's residual / scalar recipes (dist_recipe.hpp l2_general / ip_general), one lane per row
     for (uint32_t base = 0; base < cnt; base += 64) {
       const uint32_t j = base + lane;
       if (j < cnt) {
@@ -434,7 +446,7 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
       vis_commit(vis, cnt);
       c.n_dist += cnt;
       HS_LAP(c, 2);
-      wave_dists<METRIC>(ix, qv, nid, nd, cnt, lane);  // :395-396
+      wave_dists<METRIC, -1>(ix, qv, nid, nd, cnt, lane);  // :395-396
       wave_sync();
       HS_LAP(c, 3);
       uint32_t ts = st.top_size, cs = st.cand_size;
@@ -490,7 +502,7 @@ __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const
   uint32_t cur;
   float curdist;
   Visited vis;
-  descend<METRIC>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
+  descend<METRIC, -1>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
   HS_LAP(c, 5);
 
   // ---- level-0 (and threshold-level) beams ----------------------------------------------------
@@ -1090,8 +1102,11 @@ static hipError_t launch_fast_md(const DevIndex &ix, const SearchArgs &a, size_t
 hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
   const size_t lds = fast_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
   if (ix.has_deleted) {
-    if (ix.metric == METRIC_L2) return ix.dim == 128 ? launch_fast_del<METRIC_L2, 8>(ix, a, lds, stream) : launch_fast_del<METRIC_L2, 0>(ix, a, lds, stream);
-    return launch_fast_del<METRIC_IP, 0>(ix, a, lds, stream);
+    const bool odd = (ix.dim & 15u) != 0;
+    if (ix.metric == METRIC_L2)
+      return ix.dim == 128 ? launch_fast_del<METRIC_L2, 8>(ix, a, lds, stream)
+                           : (odd ? launch_fast_del<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_L2, 0>(ix, a, lds, stream));
+    return odd ? launch_fast_del<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_IP, 0>(ix, a, lds, stream);
   }
   // compile-time dims for the common shapes (the runtime-dim kernel is 1.5-1.7x slower: measured on DEEP-10M, d=96)
   if (ix.metric == METRIC_L2) {
@@ -1101,11 +1116,11 @@ hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stre
       case 960: return launch_fast_md<METRIC_L2, 60>(ix, a, lds, stream);   // GIST
       case 768: return launch_fast_md<METRIC_L2, 48>(ix, a, lds, stream);
       case 256: return launch_fast_md<METRIC_L2, 16>(ix, a, lds, stream);
-      default: return launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
+      default: return (ix.dim & 15u) ? launch_fast_md<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
     }
   }
   if (ix.dim == 768) return launch_fast_md<METRIC_IP, 48>(ix, a, lds, stream);   // COHERE / text embeddings
-  return launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
+  return (ix.dim & 15u) ? launch_fast_md<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
 }
 
 }  // namespace hs

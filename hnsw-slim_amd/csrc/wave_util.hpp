@@ -73,6 +73,59 @@ __device__ __forceinline__ float lane4_reduce(const float (&acc)[4], int sub, bo
     return 1.0f - ip;
   }
 }
+// dim % 4 == 0, dim % 16 != 0 (GloVe-100, 200, 300 ...): the reference's 4-lane recipes with one lane per accumulator --
+// lane `sub` of a 4-lane group owns TmpRes[sub] of L2SqrSIMD4Ext (space_l2.h:166-190: acc += (q-x)*(q-x) per 4-element
+// step, rounded multiply then rounded add), or ymm lanes sub / sub+4 of InnerProductSIMD4ExtAVX (space_ip.h:24-69: even
+// 4-element steps of the 16-blocks go to the low half, odd ones to the high half, lo+hi, then the remaining steps), and
+// the group sums ((a0 + a1) + a2) + a3.  Dword loads, but the four lanes read 16 contiguous bytes and the sixteen groups
+// walk sixteen rows in step, so the rows stream through the cache as in the float4 kernels.  q, x point at element `sub`.
+// Every lane of the group returns the distance.  `hook()` runs after the first round of loads has been issued.
+template <int METRIC, class Hook>
+__device__ __forceinline__ float quad_dist4(const float *q, const float *x, uint32_t dim, Hook &&hook) {
+  const uint32_t steps = dim >> 2;
+  const uint32_t lim = METRIC == METRIC_L2 ? steps : (dim >> 4) << 2;   // IP: steps inside the 16-blocks
+  float lo = 0.f, hi = 0.f;
+  for (uint32_t s0 = 0; s0 < lim; s0 += 8) {
+    const uint32_t nb = min(8u, lim - s0);
+    float buf[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++)
+      if (i < nb) buf[i] = x[(s0 + i) * 4];
+    if (s0 == 0) hook();
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++)
+      if (i < nb) {
+        const float qe = q[(s0 + i) * 4];
+        if (METRIC == METRIC_L2) {
+          const float t = qe - buf[i];
+          const float p = t * t;
+          lo = lo + p;
+        } else {
+          const float p = qe * buf[i];
+          if (i & 1) hi = hi + p; else lo = lo + p;   // s0 is a multiple of 8: parity of the step = parity of i
+        }
+      }
+  }
+  float a = lo;
+  if (METRIC == METRIC_IP) {
+    a = lo + hi;
+    float buf[3];   // dim % 16 != 0 and dim % 4 == 0: one to three steps remain
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++)
+      if (lim + i < steps) buf[i] = x[(lim + i) * 4];
+    if (lim == 0) hook();
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++)
+      if (lim + i < steps) {
+        const float p = q[(lim + i) * 4] * buf[i];
+        a = a + p;
+      }
+  }
+  const float a0 = dpp_f<0x00>(a), a1 = dpp_f<0x55>(a), a2 = dpp_f<0xAA>(a), a3 = dpp_f<0xFF>(a);   // quad_perm broadcasts
+  const float r = ((a0 + a1) + a2) + a3;
+  return METRIC == METRIC_L2 ? r : 1.0f - r;
+}
+
 template <int METRIC>
 __device__ __forceinline__ void step4(float (&acc)[4], const float4 &q4, const float4 &x4) {
   const float x[4] = {x4.x, x4.y, x4.z, x4.w};
