@@ -20,7 +20,7 @@ HS_MODE_SLIM_IDS, HS_MODE_PQ = 0, 1
 HS_OK, HS_ERR_IO, HS_ERR_CORRUPT, HS_ERR_NOMEM, HS_ERR_INVALID, HS_ERR_UNSUPPORTED, HS_ERR_DEVICE, HS_ERR_CAPACITY = range(8)
 
 EXPORTS = [
-    "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_free", "hs_set_ef", "hs_index_info",
+    "hs_last_error", "hs_device_count", "hs_index_load", "hs_index_load_mem", "hs_index_free", "hs_set_ef", "hs_index_info",
     "hs_set_capacity", "hs_set_exact_order", "hs_search_batch", "hs_search_batch_dev", "hs_search_check", "hs_search_batch_raw", "hs_search_batch_filtered", "hs_labels",
     "hs_build_hnsw", "hs_build_hnsw_labeled", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
@@ -63,6 +63,7 @@ def lib():
     L.hs_last_error.restype = ctypes.c_char_p
     L.hs_device_count.restype = ci
     L.hs_index_load.argtypes = [ctypes.c_char_p, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
+    L.hs_index_load_mem.argtypes = [ctypes.c_char_p, sz, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
     L.hs_index_free.argtypes = [vp]
     L.hs_index_free.restype = None
     L.hs_set_ef.argtypes = [vp, sz]
@@ -197,7 +198,11 @@ class Index:
         self._h = ctypes.c_void_p()
         self.kind, self.dim, self.metric, self.device = kind, dim, metric, device
         self.ef = 10
-        _check(lib().hs_index_load(path.encode(), kind, metric, dim, max_elements, device, ctypes.byref(self._h)))
+        if isinstance(path, (bytes, bytearray, memoryview)):   # the serialized index itself (hs_index_load_mem)
+            buf = bytes(path)
+            _check(lib().hs_index_load_mem(buf, len(buf), kind, metric, dim, max_elements, device, ctypes.byref(self._h)))
+        else:
+            _check(lib().hs_index_load(path.encode(), kind, metric, dim, max_elements, device, ctypes.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -239,11 +239,11 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
 
 // HierarchicalNSWSlimQ::loadIndex (hnswalg_slimq.h:1218-1313): graph -> CSR/tiles, element records -> 16-byte header
 // {f_add, f_rescale, cluster id, f_error} + sign code, rotated centroids and rotator flips as they are.
-static hs_status load_slimq(const char *path, int metric, size_t dim, int device, hs_index **out) {
+static hs_status load_slimq(const BinSource &src, int metric, size_t dim, int device, hs_index **out) {
   SlimQGraph q;
   PackedIndex p;
   try {
-    q.load(path, metric, dim);
+    q.load(src, metric, dim);
     if (q.rot.trunc < 64) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports dim >= 64");
     p.kind = HS_KIND_SLIMQ; p.metric = (Metric)metric; p.n = q.count; p.dim = dim;
     p.maxlevel = q.maxlevel; p.threshold_level = q.threshold_level; p.enterpoint = q.enterpoint;
@@ -339,9 +339,7 @@ static hs_status load_slimq(const char *path, int metric, size_t dim, int device
   return HS_OK;
 }
 
-hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements, int device,
-                        hs_index **out) {
-  if (!path || !out) return fail(HS_ERR_INVALID, "null argument");
+static hs_status load_from(const BinSource &src, int kind, int metric, size_t dim, size_t max_elements, int device, hs_index **out) {
   if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
   if (dim == 0) return fail(HS_ERR_INVALID, "dim must be > 0");
   if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
@@ -349,14 +347,14 @@ hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size
   try {
     if (kind == HS_KIND_HNSW) {
       VanillaGraph g;
-      g.load(path, (Metric)metric, dim, max_elements);
+      g.load(src, (Metric)metric, dim, max_elements);
       p.from_vanilla(g);
     } else if (kind == HS_KIND_SLIM) {
       SlimGraph g;
-      g.load(path, (Metric)metric, dim);
+      g.load(src, (Metric)metric, dim);
       p.from_slim(g);
     } else if (kind == HS_KIND_SLIMQ) {
-      return load_slimq(path, metric, dim, device, out);
+      return load_slimq(src, metric, dim, device, out);
     } else {
       return fail(HS_ERR_INVALID, "bad index kind");
     }
@@ -371,6 +369,18 @@ hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size
   if (s != HS_OK) { delete ix; return s; }
   *out = ix;
   return HS_OK;
+}
+
+hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements, int device,
+                        hs_index **out) {
+  if (!path || !out) return fail(HS_ERR_INVALID, "null argument");
+  return load_from(BinSource(path), kind, metric, dim, max_elements, device, out);
+}
+
+hs_status hs_index_load_mem(const void *bytes, size_t len, int kind, int metric, size_t dim, size_t max_elements, int device,
+                            hs_index **out) {
+  if (!bytes || !out) return fail(HS_ERR_INVALID, "null argument");
+  return load_from(BinSource(bytes, len), kind, metric, dim, max_elements, device, out);
 }
 
 void hs_index_free(hs_index *ix) {

@@ -32,10 +32,36 @@ using pairfi = std::pair<float, uint32_t>;
 struct CmpFirst { bool operator()(const pairfi &a, const pairfi &b) const { return a.first < b.first; } };  // hnswalg.h:176-182
 using MaxQ = std::priority_queue<pairfi, std::vector<pairfi>, CmpFirst>;
 
+// Where a serialized index comes from: a file, or the same bytes already in host memory (hs_index_load_mem).
+struct BinSource {
+  std::string path;
+  const char *mem = nullptr;
+  size_t len = 0;
+  BinSource(const std::string &p) : path(p) {}
+  BinSource(const char *p) : path(p) {}
+  BinSource(const void *m, size_t n) : mem((const char *)m), len(n) {}
+};
+struct MemBuf : std::streambuf {
+  MemBuf(const char *b, size_t n) { setg(const_cast<char *>(b), const_cast<char *>(b), const_cast<char *>(b) + n); }
+  pos_type seekoff(off_type off, std::ios_base::seekdir dir, std::ios_base::openmode) override {
+    char *base = eback(), *end = egptr();
+    char *to = dir == std::ios_base::beg ? base + off : dir == std::ios_base::end ? end + off : gptr() + off;
+    if (to < base || to > end) return pos_type(off_type(-1));
+    setg(base, to, end);
+    return pos_type(to - base);
+  }
+  pos_type seekpos(pos_type pos, std::ios_base::openmode m) override { return seekoff(off_type(pos), std::ios_base::beg, m); }
+};
 struct BinReader {
-  std::ifstream in;
-  explicit BinReader(const std::string &p) : in(p, std::ios::binary) {
-    if (!in.is_open()) throw std::runtime_error("Cannot open file");
+  std::ifstream file;
+  MemBuf mb;
+  std::istream mem_in;
+  std::istream &in;
+  explicit BinReader(const BinSource &s) : mb(s.mem, s.mem ? s.len : 0), mem_in(&mb), in(s.mem ? mem_in : static_cast<std::istream &>(file)) {
+    if (!s.mem) {
+      file.open(s.path, std::ios::binary);
+      if (!file.is_open()) throw std::runtime_error("Cannot open file");
+    }
   }
   template <typename T> T pod() {
     T v;
@@ -343,8 +369,8 @@ struct VanillaGraph {
     }
   }
 
-  void load(const std::string &path, Metric m, size_t d, size_t max_elements_i = 0) {  // hnswalg.h:781-893
-    BinReader r(path);
+  void load(const BinSource &src, Metric m, size_t d, size_t max_elements_i = 0) {  // hnswalg.h:781-893
+    BinReader r(src);
     r.in.seekg(0, r.in.end);
     std::streamoff total = r.in.tellg();
     r.in.seekg(0, r.in.beg);
@@ -540,8 +566,8 @@ struct SlimGraph {
     }
   }
 
-  void load(const std::string &path, Metric m, size_t d) {  // hnswalg_slim.h:753-815
-    BinReader r(path);
+  void load(const BinSource &src, Metric m, size_t d) {  // hnswalg_slim.h:753-815
+    BinReader r(src);
     metric = m; dim = d;
     count = r.pod<uint64_t>();
     size_per_el = r.pod<uint64_t>();

@@ -273,8 +273,8 @@ struct SlimQGraph {
     }
   }
 
-  void load(const std::string &path, int metric_expected, size_t d) {  // hnswalg_slimq.h:1218-1313
-    BinReader r(path);
+  void load(const BinSource &src, int metric_expected, size_t d) {  // hnswalg_slimq.h:1218-1313
+    BinReader r(src);
     count = r.pod<uint64_t>();
     const uint64_t spe = r.pod<uint64_t>();
     const uint64_t label_off = r.pod<uint64_t>(), off_total = r.pod<uint64_t>(), off_data = r.pod<uint64_t>(), off_nb = r.pod<uint64_t>();

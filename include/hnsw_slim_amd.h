@@ -68,6 +68,11 @@ int hs_device_count(void);
  * `device`.  ef starts at 10 as in the reference.  Both metrics take every dim. */
 hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements,
                         int device, hs_index **out);
+/* The same, from the serialized bytes already in host memory (what saveIndex would have written: hnswalg.h:748-779,
+ * hnswalg_slim.h:717-751, hnswalg_slimq.h:1161-1216) -- for hosts that receive the index over a socket
+ * (hnsw_slim_server.cc:59-81) or keep it in a buffer; nothing is written to disk.  The bytes are not retained. */
+hs_status hs_index_load_mem(const void *bytes, size_t len, int kind, int metric, size_t dim, size_t max_elements,
+                            int device, hs_index **out);
 void hs_index_free(hs_index *ix);                        /* ~HierarchicalNSW* / clear(): hnswalg_slim.h:154-167 */
 hs_status hs_set_ef(hs_index *ix, size_t ef);            /* setEf: hnswalg.h:184, hnswalg_slim.h:193 */
 hs_status hs_index_info(const hs_index *ix, hs_info *out);

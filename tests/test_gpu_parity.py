@@ -198,6 +198,42 @@ def test_slim_inner_product_off_the_simd16_path(hs, oracle, tmp_path, dim):
     _slim_case(hs, oracle, tmp_path, base.astype(np.float32), q.astype(np.float32), dim, IP, 16, 100, [32, 100])
 
 
+def test_load_from_memory_equals_load_from_file(hs, oracle, tmp_path):
+    """hs_index_load_mem: the serialized bytes in a host buffer (vanilla, Slim, SlimQ) give the same index as the file; a
+    truncated buffer reports the reference's corruption error."""
+    g = np.load(os.path.join(GOLDEN, "l2_cont_d32.npz"))
+    hp = os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin")
+    q = g["queries"]
+    a, b = hs.Index(hp, hs.HS_KIND_HNSW, 32), hs.Index(open(hp, "rb").read(), hs.HS_KIND_HNSW, 32)
+    for ix in (a, b):
+        ix.set_ef(32)
+    ra, rb = a.search_pq(q, 10), b.search_pq(q, 10)
+    assert np.array_equal(ra["labels"], rb["labels"]) and ra["dists"].tobytes() == rb["dists"].tobytes()
+    assert a.info() == b.info()
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(hp, sp, 32)
+    a, b = hs.Index(sp, hs.HS_KIND_SLIM, 32), hs.Index(open(sp, "rb").read(), hs.HS_KIND_SLIM, 32)
+    for ix in (a, b):
+        ix.set_ef(48)
+    assert np.array_equal(a.search_ids(q, 10)["labels"], b.search_ids(q, 10)["labels"])
+    base = mixture(1500, 64, 91)
+    h64, s64, q64 = str(tmp_path / "h64.bin"), str(tmp_path / "s64.bin"), str(tmp_path / "q64.bin")
+    hs.build_hnsw(base, h64, M=8, ef_construction=60, threads=8)
+    hs.convert_slim(h64, s64, 64, threads=8)
+    hs.convert_slimq(s64, 0, 64, base[:4].copy(), q64, threads=8)
+    qq = mixture(50, 64, 92)
+    outs = []
+    for src in (q64, open(q64, "rb").read()):
+        ix = hs.Index(src, hs.HS_KIND_SLIMQ, 64)
+        ix.slimq_set_dataset(base)
+        ix.slimq_set_tconst(7.0)
+        ix.set_ef(40)
+        outs.append(ix.slimq_search(qq, 10)["labels"])
+    assert np.array_equal(outs[0], outs[1])
+    with pytest.raises(hs.HsError, match="corrupted or unsupported"):
+        hs.Index(open(sp, "rb").read()[:3000], hs.HS_KIND_SLIM, 32)
+
+
 def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
     """hnswlib-API caller (tests/facade_smoke.cpp): per-query searchKnn(q,k,tableint*) loop + searchKnnBatch on
     a Slim index, and searchKnnCloserFirst on a vanilla index, against the oracle."""
