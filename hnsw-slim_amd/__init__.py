@@ -38,7 +38,7 @@ class HsInfo(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("dim", ctypes.c_uint64), ("kind", ctypes.c_int32), ("metric", ctypes.c_int32),
                 ("maxlevel", ctypes.c_int32), ("threshold_level", ctypes.c_int32), ("enterpoint", ctypes.c_uint32),
                 ("has_deleted", ctypes.c_int32), ("n_edges", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64),
-                ("max_degree0", ctypes.c_uint64)]
+                ("max_degree0", ctypes.c_uint64), ("index_size", ctypes.c_uint64)]
 
 
 def build_library(force=False):

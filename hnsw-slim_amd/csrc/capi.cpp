@@ -231,7 +231,7 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   hs_info &i = ix->info;
   i.n = p.n; i.dim = p.dim; i.kind = p.kind; i.metric = p.metric; i.maxlevel = p.maxlevel;
   i.threshold_level = p.threshold_level; i.enterpoint = p.enterpoint; i.has_deleted = p.has_deleted;
-  i.n_edges = p.cols.size(); i.max_degree0 = p.max_deg0;
+  i.n_edges = p.cols.size(); i.max_degree0 = p.max_deg0; i.index_size = p.index_size;
   i.device_bytes = p.vec.size() * 4 + (p.row_ptr0.size() + p.cols.size() + p.up_base.size() + p.up_ptr.size()) * 4 +
                    p.labels.size() * 8 + p.deleted.size() + (size_t)p.n * stride * 4;
   return HS_OK;
@@ -247,6 +247,8 @@ static hs_status load_slimq(const BinSource &src, int metric, size_t dim, int de
     if (q.rot.trunc < 64) return fail(HS_ERR_UNSUPPORTED, "SlimQ supports dim >= 64");
     p.kind = HS_KIND_SLIMQ; p.metric = (Metric)metric; p.n = q.count; p.dim = dim;
     p.maxlevel = q.maxlevel; p.threshold_level = q.threshold_level; p.enterpoint = q.enterpoint;
+    p.index_size = q.count * 20;   // HierarchicalNSWSlimQ::indexSize() (hnswalg_slimq.h:2047-2057): 20 B per element + blobs
+    for (size_t i = 0; i < q.count; i++) p.index_size += 2 * (size_t)q.level[i] + 4 * (size_t)q.total(i);
     p.labels = q.label;
     p.deleted.assign(q.count, 0);
     p.pack_chal([&](size_t i) { return (int)q.level[i]; }, [&](size_t i) { return (size_t)q.total(i); },

@@ -604,6 +604,7 @@ struct PackedIndex {
   uint32_t enterpoint = 0;
   bool has_deleted = false;
   size_t max_deg0 = 0;
+  size_t index_size = 0;   // what the reference's indexSize() reports for this index (graph structure without vectors)
   std::vector<float> vec;
   std::vector<uint32_t> row_ptr0, cols, up_base, up_ptr;
   std::vector<uint64_t> labels;
@@ -613,6 +614,10 @@ struct PackedIndex {
 
   void from_vanilla(const VanillaGraph &g) {
     kind = 0; metric = g.metric; n = g.count; dim = g.dim;
+    // HierarchicalNSW::indexSize() (hnswalg.h:1533-1547): level-0 block without vectors and labels, element_levels_,
+    // one pointer per element + its upper link lists (+1 as malloc'd)
+    index_size = g.max_elements * (g.size_per_el - g.dim * 4 - 8) + g.max_elements * sizeof(int);
+    for (size_t i = 0; i < g.count; i++) index_size += 8 + (g.levels[i] > 0 ? g.size_links_up * (size_t)g.levels[i] + 1 : 0);
     maxlevel = g.maxlevel; threshold_level = 0; enterpoint = g.enterpoint;
     vec.resize(n * dim); labels.resize(n); deleted.resize(n);
     row_ptr0.assign(n + 1, 0); up_base.assign(n, NONE); up_ptr.clear(); cols.clear();
@@ -686,6 +691,9 @@ struct PackedIndex {
 
   void from_slim(const SlimGraph &g) {
     kind = 1; metric = g.metric; n = g.count; dim = g.dim;
+    // HierarchicalNSWSlim::indexSize() (hnswalg_slim.h:2435-2444): 16 bytes per element + every neighbour blob
+    index_size = g.count * 16;
+    for (size_t i = 0; i < g.count; i++) index_size += 2 * (size_t)g.level((uint32_t)i) + 4 * (size_t)g.total((uint32_t)i);
     maxlevel = g.maxlevel; threshold_level = g.threshold_level; enterpoint = g.enterpoint;
     has_deleted = g.has_deleted;
     vec.resize(n * dim); labels.resize(n); deleted.resize(n);

@@ -127,6 +127,21 @@ class DeviceIndex {
   }
   hs_index *handle() const { return h_; }
   const std::string &path() const { return path_; }
+  // indexSize(): the bytes the reference reports for this index's graph structure in ITS layout (hnswalg.h:1533-1547,
+  // hnswalg_slim.h:2435-2444, hnswalg_slimq.h:2047-2057), so that the strategies' "index size" lines keep their meaning
+  // (hnsw_slim_strategy.h:83,99); deviceBytes() is what the index holds in HBM here.
+  size_t indexSize() const {
+    if (!h_) return 0;
+    hs_info info;
+    check(hs_index_info(h_, &info));
+    return (size_t)info.index_size;
+  }
+  size_t deviceBytes() const {
+    if (!h_) return 0;
+    hs_info info;
+    check(hs_index_info(h_, &info));
+    return (size_t)info.device_bytes;
+  }
 
  protected:
   void load(const std::string &location, int kind, SpaceInterface<float> *s, size_t max_elements) {
@@ -206,6 +221,7 @@ class HierarchicalNSW<float> : public AlgorithmInterface<float>, public detail::
  public:
   ~HierarchicalNSW() { if (!tmp_path_.empty()) unlink(tmp_path_.c_str()); }
   void build() const { ensure_built(); }   // force the deferred build (convertFromHNSW calls it)
+  size_t indexSize() const { ensure_built(); return detail::DeviceIndex::indexSize(); }
   explicit HierarchicalNSW(SpaceInterface<float> *s) : space_(s) {}
   HierarchicalNSW(SpaceInterface<float> *s, const std::string &location, bool /*nmslib*/ = false, size_t max_elements = 0,
                   bool /*allow_replace_deleted*/ = false) : space_(s) {

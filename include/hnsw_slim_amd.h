@@ -55,6 +55,8 @@ typedef struct {
   uint64_t n_edges;      /* entries of the CSR column array (all levels) */
   uint64_t device_bytes; /* HBM held by this index */
   uint64_t max_degree0;
+  uint64_t index_size;   /* the reference's indexSize() for this index: hnswalg.h:1533-1547, hnswalg_slim.h:2435-2444,
+                            hnswalg_slimq.h:2047-2057 (graph structure of the CPU layout, without the vectors) */
 } hs_info;
 
 const char *hs_last_error(void);

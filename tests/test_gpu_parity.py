@@ -234,6 +234,33 @@ def test_load_from_memory_equals_load_from_file(hs, oracle, tmp_path):
         hs.Index(open(sp, "rb").read()[:3000], hs.HS_KIND_SLIM, 32)
 
 
+def test_index_size_is_the_references_formula(hs, tmp_path):
+    """hs_info.index_size = indexSize() of the reference classes (hnswalg.h:1533-1547, hnswalg_slim.h:2435-2444), checked
+    against an independent parse of the files."""
+    import struct
+    hp = os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin")
+    raw = open(hp, "rb").read()
+    off0, max_el, cnt, spe, label_off, off_data, maxlevel, ep, maxM, maxM0, M, mult, efc = struct.unpack_from("<6QiI3QdQ", raw, 0)
+    pos = struct.calcsize("<6QiI3QdQ") + cnt * spe
+    size_links_up = 4 + 4 * maxM
+    want = max_el * (spe - 32 * 4 - 8) + max_el * 4
+    for _ in range(cnt):
+        (sz,) = struct.unpack_from("<I", raw, pos)
+        pos += 4 + sz
+        want += 8 + (sz + 1 if sz else 0)
+        assert sz % size_links_up == 0
+    assert pos == len(raw)
+    assert hs.Index(hp, hs.HS_KIND_HNSW, 32).info()["index_size"] == want
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(hp, sp, 32)
+    raw = open(sp, "rb").read()
+    n, spe = struct.unpack_from("<2Q", raw, 0)
+    el = np.frombuffer(raw, np.uint8, n * spe, 93).reshape(n, spe)
+    level = el[:, 0:4].copy().view(np.int32)[:, 0].astype(np.int64)
+    total = el[:, 4:8].copy().view(np.uint32)[:, 0].astype(np.int64)
+    assert hs.Index(sp, hs.HS_KIND_SLIM, 32).info()["index_size"] == 16 * n + int((2 * level + 4 * total).sum())
+
+
 def test_cpp_facade_matches_oracle(hs, oracle, tmp_path):
     """hnswlib-API caller (tests/facade_smoke.cpp): per-query searchKnn(q,k,tableint*) loop + searchKnnBatch on
     a Slim index, and searchKnnCloserFirst on a vanilla index, against the oracle."""
