@@ -1108,7 +1108,7 @@ hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stre
                            : (odd ? launch_fast_del<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_L2, 0>(ix, a, lds, stream));
     return odd ? launch_fast_del<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_IP, 0>(ix, a, lds, stream);
   }
-  // compile-time dims for the common shapes (the runtime-dim kernel is 1.5-1.7x slower: measured on DEEP-10M, d=96)
+  // compile-time dims for the common shapes (the runtime-dim kernel is 1.15-1.7x slower: measured at d=64 and on DEEP-10M, d=96)
   if (ix.metric == METRIC_L2) {
     switch (ix.dim) {
       case 128: return launch_fast_md<METRIC_L2, 8>(ix, a, lds, stream);    // SIFT
@@ -1116,10 +1116,19 @@ hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stre
       case 960: return launch_fast_md<METRIC_L2, 60>(ix, a, lds, stream);   // GIST
       case 768: return launch_fast_md<METRIC_L2, 48>(ix, a, lds, stream);
       case 256: return launch_fast_md<METRIC_L2, 16>(ix, a, lds, stream);
+      case 64: return launch_fast_md<METRIC_L2, 4>(ix, a, lds, stream);
+      case 512: return launch_fast_md<METRIC_L2, 32>(ix, a, lds, stream);
+      case 1024: return launch_fast_md<METRIC_L2, 64>(ix, a, lds, stream);
       default: return (ix.dim & 15u) ? launch_fast_md<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
     }
   }
-  if (ix.dim == 768) return launch_fast_md<METRIC_IP, 48>(ix, a, lds, stream);   // COHERE / text embeddings
+  switch (ix.dim) {   // text / image embeddings
+    case 768: return launch_fast_md<METRIC_IP, 48>(ix, a, lds, stream);    // COHERE
+    case 512: return launch_fast_md<METRIC_IP, 32>(ix, a, lds, stream);
+    case 1024: return launch_fast_md<METRIC_IP, 64>(ix, a, lds, stream);
+    case 1536: return launch_fast_md<METRIC_IP, 96>(ix, a, lds, stream);
+    default: break;
+  }
   return (ix.dim & 15u) ? launch_fast_md<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
 }
 

@@ -179,6 +179,18 @@ def test_k_larger_than_ef_and_k_equals_n(hs, oracle, tmp_path):
     assert ix.info()["n"] == 500
 
 
+@pytest.mark.parametrize("dim,metric", [(64, L2), (512, L2), (1024, L2), (512, IP), (1024, IP), (1536, IP), (160, L2), (384, IP)])
+def test_slim_compiled_in_and_runtime_dims(hs, oracle, tmp_path, dim, metric):
+    """dim % 16 == 0 shapes: the ones with their own kernel instantiation (64, 512, 1024 / IP 512, 1024, 1536) and two that
+    take the runtime-dim kernel (160, 384)."""
+    base = mixture(2500, dim, 71, lo=-1, hi=1, sigma=0.5)
+    q = mixture(60, dim, 72, lo=-1, hi=1, sigma=0.5)
+    if metric == IP:
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    _slim_case(hs, oracle, tmp_path, base.astype(np.float32), q.astype(np.float32), dim, metric, 16, 100, [32, 100, 200])
+
+
 @pytest.mark.parametrize("dim", (100, 70, 36, 12))
 def test_slim_dims_off_the_simd16_path(hs, oracle, tmp_path, dim):
     """dim % 16 != 0: the reference's SIMD4 (d=100) and SIMD16+residual (d=70) L2 recipes, strict and fast kernels."""
