@@ -81,6 +81,20 @@ __host__ __device__ inline FastLds fast_layout(uint32_t dim, uint32_t ef, uint32
   l.total = l.off_stage + align_up(ef * 8, 16);
   return l;
 }
+// The build compiles this file twice, side by side: -DHS_TU_METRIC=0 holds the L2 kernels and everything that is not
+// per metric, -DHS_TU_METRIC=1 the inner-product kernels (the kernel instantiations are the build's critical path).
+// Without the macro one translation unit holds both (make asm / prof / asan).
+#if !defined(HS_TU_METRIC)
+#define HS_TU_HAS_L2 1
+#define HS_TU_HAS_IP 1
+#elif HS_TU_METRIC == 0
+#define HS_TU_HAS_L2 1
+#define HS_TU_HAS_IP 0
+#else
+#define HS_TU_HAS_L2 0
+#define HS_TU_HAS_IP 1
+#endif
+#if HS_TU_HAS_L2
 size_t strict_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) {
   return strict_layout(dim, ef, cand_cap, hash_slots).total;
 }
@@ -91,6 +105,7 @@ bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
   // ef == k runs the boundary-watching variant, compiled for ef <= 128 only
   return ix.tile0 != nullptr && ix.threshold_level == 0 && (ef > k || (ef == k && ef <= 128 && !ix.has_deleted)) && ef <= 512;
 }
+#endif
 
 struct Counters {
   uint32_t n_dist, n_hops, n_nbr;
@@ -1074,11 +1089,28 @@ static hipError_t launch(K kern, const DevIndex &ix, const SearchArgs &a, size_t
   return hipGetLastError();
 }
 
+hipError_t launch_strict_l2(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream);
+hipError_t launch_strict_ip(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream);
+hipError_t launch_fast_l2(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream);
+hipError_t launch_fast_ip(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream);
+#if HS_TU_HAS_L2
+hipError_t launch_strict_l2(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
+  return launch(strict_kernel<METRIC_L2>, ix, a, lds, stream);
+}
 hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
   const size_t lds = strict_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
-  return ix.metric == METRIC_L2 ? launch(strict_kernel<METRIC_L2>, ix, a, lds, stream)
-                                : launch(strict_kernel<METRIC_IP>, ix, a, lds, stream);
+  return ix.metric == METRIC_L2 ? launch_strict_l2(ix, a, lds, stream) : launch_strict_ip(ix, a, lds, stream);
 }
+hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
+  const size_t lds = fast_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
+  return ix.metric == METRIC_L2 ? launch_fast_l2(ix, a, lds, stream) : launch_fast_ip(ix, a, lds, stream);
+}
+#endif
+#if HS_TU_HAS_IP
+hipError_t launch_strict_ip(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
+  return launch(strict_kernel<METRIC_IP>, ix, a, lds, stream);
+}
+#endif
 
 // delete marks / filters: the variant with the reference's !bare_bone branches (runtime-dim and d=128 only)
 template <int METRIC, int D16>
@@ -1099,37 +1131,38 @@ static hipError_t launch_fast_md(const DevIndex &ix, const SearchArgs &a, size_t
   if (a.ef <= 256) return launch(fast_kernel<METRIC, 4, D16>, ix, a, lds, stream);
   return launch(fast_kernel<METRIC, 8, D16>, ix, a, lds, stream);
 }
-hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
-  const size_t lds = fast_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
+#if HS_TU_HAS_L2
+hipError_t launch_fast_l2(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
   if (ix.has_deleted) {
-    const bool odd = (ix.dim & 15u) != 0;
-    if (ix.metric == METRIC_L2)
-      return ix.dim == 128 ? launch_fast_del<METRIC_L2, 8>(ix, a, lds, stream)
-                           : (odd ? launch_fast_del<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_L2, 0>(ix, a, lds, stream));
-    return odd ? launch_fast_del<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_IP, 0>(ix, a, lds, stream);
+    if (ix.dim == 128) return launch_fast_del<METRIC_L2, 8>(ix, a, lds, stream);
+    return (ix.dim & 15u) ? launch_fast_del<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_L2, 0>(ix, a, lds, stream);
   }
   // compile-time dims for the common shapes (the runtime-dim kernel is 1.15-1.7x slower: measured at d=64 and on DEEP-10M, d=96)
-  if (ix.metric == METRIC_L2) {
-    switch (ix.dim) {
-      case 128: return launch_fast_md<METRIC_L2, 8>(ix, a, lds, stream);    // SIFT
-      case 96: return launch_fast_md<METRIC_L2, 6>(ix, a, lds, stream);     // DEEP
-      case 960: return launch_fast_md<METRIC_L2, 60>(ix, a, lds, stream);   // GIST
-      case 768: return launch_fast_md<METRIC_L2, 48>(ix, a, lds, stream);
-      case 256: return launch_fast_md<METRIC_L2, 16>(ix, a, lds, stream);
-      case 64: return launch_fast_md<METRIC_L2, 4>(ix, a, lds, stream);
-      case 512: return launch_fast_md<METRIC_L2, 32>(ix, a, lds, stream);
-      case 1024: return launch_fast_md<METRIC_L2, 64>(ix, a, lds, stream);
-      default: return (ix.dim & 15u) ? launch_fast_md<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
-    }
+  switch (ix.dim) {
+    case 128: return launch_fast_md<METRIC_L2, 8>(ix, a, lds, stream);    // SIFT
+    case 96: return launch_fast_md<METRIC_L2, 6>(ix, a, lds, stream);     // DEEP
+    case 960: return launch_fast_md<METRIC_L2, 60>(ix, a, lds, stream);   // GIST
+    case 768: return launch_fast_md<METRIC_L2, 48>(ix, a, lds, stream);
+    case 256: return launch_fast_md<METRIC_L2, 16>(ix, a, lds, stream);
+    case 64: return launch_fast_md<METRIC_L2, 4>(ix, a, lds, stream);
+    case 512: return launch_fast_md<METRIC_L2, 32>(ix, a, lds, stream);
+    case 1024: return launch_fast_md<METRIC_L2, 64>(ix, a, lds, stream);
+    default: return (ix.dim & 15u) ? launch_fast_md<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
   }
+}
+#endif
+#if HS_TU_HAS_IP
+hipError_t launch_fast_ip(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
+  if (ix.has_deleted)
+    return (ix.dim & 15u) ? launch_fast_del<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_del<METRIC_IP, 0>(ix, a, lds, stream);
   switch (ix.dim) {   // text / image embeddings
     case 768: return launch_fast_md<METRIC_IP, 48>(ix, a, lds, stream);    // COHERE
     case 512: return launch_fast_md<METRIC_IP, 32>(ix, a, lds, stream);
     case 1024: return launch_fast_md<METRIC_IP, 64>(ix, a, lds, stream);
     case 1536: return launch_fast_md<METRIC_IP, 96>(ix, a, lds, stream);
-    default: break;
+    default: return (ix.dim & 15u) ? launch_fast_md<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
   }
-  return (ix.dim & 15u) ? launch_fast_md<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
 }
+#endif
 
 }  // namespace hs
