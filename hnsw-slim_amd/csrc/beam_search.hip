@@ -210,7 +210,8 @@ __device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
 
 // Distances query -> rows nid[0..cnt), 16 rows per pass, 4 lanes per row; nd[j] receives the value.
 // D16 = dim/16 when known at compile time (d=128 -> 8: eight 16-byte loads per lane, fully unrolled), 0 = runtime dim
-// with dim % 16 == 0, -1 = any runtime dim (adds the recipes for dim % 16 != 0; those instantiations carry their cost).
+// with dim % 16 == 0, -1 = any runtime dim (adds the recipes for dim % 16 != 0; those instantiations carry their cost),
+// -dim/4 (< -1) = a compiled-in dim % 4 == 0 shape off the SIMD16 path (-25: d = 100).
 // `between()` runs after the first pass's row loads have been ISSUED and before they are
 // consumed: LDS-only work placed there (the candidate heap's pop) hides under the HBM latency.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
@@ -222,18 +223,20 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
                                             uint32_t cnt, int lane, Hook between = Hook()) {
   const int sub = lane & 3, grp = lane >> 2;
   float out = FLT_MAX;
-  if (D16 < 0 && (ix.dim & 15u) && !(ix.dim & 3u)) {
+  constexpr uint32_t kQuadDim = D16 < -1 ? (uint32_t)(-D16) * 4u : 0u;   // D16 = -dim/4: a compiled-in dim % 4 == 0 shape
+  const uint32_t qdim = kQuadDim ? kQuadDim : ix.dim;
+  if (D16 < 0 && (qdim & 15u) && !(qdim & 3u)) {
     // dim % 4 == 0: the reference's 4-lane recipes, 4 lanes per row and 16 rows per pass (wave_util.hpp quad_dist4)
     for (uint32_t base = 0; base < cnt; base += 16) {
       const uint32_t j = base + grp;
       const bool act = j < cnt;
       const uint32_t id = nid[act ? j : 0];
-      const float r = quad_dist4<METRIC>(qv + sub, ix.vec + (size_t)id * ix.dim + sub, ix.dim, [&]() { if (base == 0) between(); });
+      const float r = quad_dist4<METRIC>(qv + sub, ix.vec + (size_t)id * qdim + sub, qdim, [&]() { if (base == 0) between(); });
       if (act && sub == 0) nd[j] = r;
     }
     return out;
   }
-  if (D16 < 0 && (ix.dim & 15u)) {
+  if (D16 == -1 && (ix.dim & 15u)) {
     // other dims: the reference's residual / scalar recipes (dist_recipe.hpp l2_general / ip_general), one lane per row
     for (uint32_t base = 0; base < cnt; base += 64) {
       const uint32_t j = base + lane;
@@ -1147,6 +1150,9 @@ hipError_t launch_fast_l2(const DevIndex &ix, const SearchArgs &a, size_t lds, h
     case 64: return launch_fast_md<METRIC_L2, 4>(ix, a, lds, stream);
     case 512: return launch_fast_md<METRIC_L2, 32>(ix, a, lds, stream);
     case 1024: return launch_fast_md<METRIC_L2, 64>(ix, a, lds, stream);
+    // GloVe-100-like: the 4-lane recipes with the dim compiled in (the 25 steps unroll without spills; at 200 / 300 the
+    // unrolled loads spill 80 / 250 B per lane, so those stay on the runtime-dim kernel)
+    case 100: return launch_fast_md<METRIC_L2, -25>(ix, a, lds, stream);
     default: return (ix.dim & 15u) ? launch_fast_md<METRIC_L2, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_L2, 0>(ix, a, lds, stream);
   }
 }
@@ -1160,6 +1166,7 @@ hipError_t launch_fast_ip(const DevIndex &ix, const SearchArgs &a, size_t lds, h
     case 512: return launch_fast_md<METRIC_IP, 32>(ix, a, lds, stream);
     case 1024: return launch_fast_md<METRIC_IP, 64>(ix, a, lds, stream);
     case 1536: return launch_fast_md<METRIC_IP, 96>(ix, a, lds, stream);
+    case 100: return launch_fast_md<METRIC_IP, -25>(ix, a, lds, stream);   // GloVe-100-angular-like, as for L2
     default: return (ix.dim & 15u) ? launch_fast_md<METRIC_IP, -1>(ix, a, lds, stream) : launch_fast_md<METRIC_IP, 0>(ix, a, lds, stream);
   }
 }

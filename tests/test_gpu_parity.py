@@ -191,7 +191,7 @@ def test_slim_compiled_in_and_runtime_dims(hs, oracle, tmp_path, dim, metric):
     _slim_case(hs, oracle, tmp_path, base.astype(np.float32), q.astype(np.float32), dim, metric, 16, 100, [32, 100, 200])
 
 
-@pytest.mark.parametrize("dim", (100, 70, 36, 12))
+@pytest.mark.parametrize("dim", (100, 200, 300, 70, 36, 12))
 def test_slim_dims_off_the_simd16_path(hs, oracle, tmp_path, dim):
     """dim % 16 != 0: the reference's SIMD4 (d=100) and SIMD16+residual (d=70) L2 recipes, strict and fast kernels."""
     base = mixture(6000, dim, 61, integer=True)
@@ -199,7 +199,7 @@ def test_slim_dims_off_the_simd16_path(hs, oracle, tmp_path, dim):
     _slim_case(hs, oracle, tmp_path, base, q, dim, L2, 16, 100, [32, 100])
 
 
-@pytest.mark.parametrize("dim", (100, 70, 36, 12, 7, 3))
+@pytest.mark.parametrize("dim", (100, 200, 300, 70, 36, 12, 7, 3))
 def test_slim_inner_product_off_the_simd16_path(hs, oracle, tmp_path, dim):
     """InnerProductSpace with dim % 16 != 0 (space_ip.h:374-382): SIMD4ExtAVX (100), SIMD16 + scalar rest (70), SIMD4 +
     scalar rest (7), scalar (3) -- strict and fast kernels, unit-norm rows."""
