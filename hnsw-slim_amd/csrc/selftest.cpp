@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "heap_emul.hpp"
+#include "host_graph.hpp"
 
 using P = std::pair<float, uint32_t>;
 struct LessP { bool operator()(const P &a, const P &b) const { return a.first < b.first; } };
@@ -78,7 +79,47 @@ static int run_nth(unsigned seed, int range) {
   return 0;
 }
 
-int main() {
+// selftest loadmem <vanilla index> <slim index> <dim>: the loaders read the serialized bytes from host memory
+// (BinSource / MemBuf, behind hs_index_load_mem) exactly as they read the files; a truncated buffer is rejected.
+static std::vector<char> slurp(const char *path) {
+  std::ifstream in(path, std::ios::binary);
+  return std::vector<char>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+}
+static int run_loadmem(const char *vanilla, const char *slim, size_t dim) {
+  const std::vector<char> vb = slurp(vanilla), sb = slurp(slim);
+  if (vb.empty() || sb.empty()) return 1;
+  hs::VanillaGraph a, b;
+  a.load(vanilla, hs::METRIC_L2, dim);
+  b.load(hs::BinSource(vb.data(), vb.size()), hs::METRIC_L2, dim);
+  if (a.count != b.count || a.maxlevel != b.maxlevel || a.enterpoint != b.enterpoint || a.level0 != b.level0 || a.links != b.links ||
+      a.levels != b.levels)
+    return 2;
+  hs::SlimGraph c, d;
+  c.load(slim, hs::METRIC_L2, dim);
+  d.load(hs::BinSource(sb.data(), sb.size()), hs::METRIC_L2, dim);
+  if (c.count != d.count || c.maxlevel != d.maxlevel || c.enterpoint != d.enterpoint || c.elements != d.elements || c.blobs != d.blobs)
+    return 3;
+  for (size_t cut : {sb.size() / 2, sb.size() - 1, (size_t)40}) {
+    try {
+      hs::SlimGraph e;
+      e.load(hs::BinSource(sb.data(), cut), hs::METRIC_L2, dim);
+      return 4;   // a truncated image must not load
+    } catch (std::runtime_error &ex) {
+      if (std::string(ex.what()) != "Index seems to be corrupted or unsupported") return 5;
+    }
+  }
+  try {
+    hs::VanillaGraph e;
+    e.load(hs::BinSource(vb.data(), vb.size() / 3), hs::METRIC_L2, dim);
+    return 6;
+  } catch (std::runtime_error &) {
+  }
+  printf("loaders: memory image == file (vanilla n=%zu, slim n=%zu); truncated images rejected\n", a.count, c.count);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc == 5 && std::string(argv[1]) == "loadmem") return run_loadmem(argv[2], argv[3], (size_t)atoll(argv[4]));
   int rc = 0;
   for (unsigned seed = 1; seed <= 8 && !rc; seed++)
     for (int range : {3, 17, 1000, 1 << 20}) {

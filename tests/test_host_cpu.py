@@ -103,6 +103,16 @@ def test_slim_convert_roundtrip(hs, oracle, tmp_path):
     assert hits / gt.size > 0.8
 
 
+def test_loaders_read_a_memory_image_like_the_file(hs, tmp_path):
+    """BinSource / MemBuf (behind hs_index_load_mem): same graphs from bytes in memory as from the file; truncation rejected."""
+    exe = os.path.join(ROOT, "hnsw-slim_amd", "selftest")
+    hp = os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin")
+    sp = str(tmp_path / "s.bin")
+    hs.convert_slim(hp, sp, 32)
+    out = subprocess.run([exe, "loadmem", hp, sp, "32"], capture_output=True, text=True)
+    assert out.returncode == 0, f"rc={out.returncode} {out.stdout} {out.stderr}"
+
+
 def test_error_conventions(hs, tmp_path):
     with pytest.raises(hs.HsError, match="dim must be > 0"):
         hs.Index(str(tmp_path / "x"), hs.HS_KIND_SLIM, 0, hs.HS_METRIC_IP)
