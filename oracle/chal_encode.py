@@ -1,0 +1,122 @@
+"""oracle/chal_encode.py -- TEST INFRASTRUCTURE ONLY (never imported by the product).
+
+An independent Python `struct` writer of the HierarchicalNSWSlim index file format
+(/root/reference/third_party/hnswlib/hnswalg_slim.h:717-751, read back by :753-815), used to
+
+  * cross-pin the Slim class to outputs of the COMPILED reference: `vanilla_to_slim_verbatim` re-encodes a vanilla
+    hnswlib index file (hnswalg.h:748-779; the golden ones are written by the compiled reference itself) as a Slim file
+    with every level's neighbour list kept verbatim and in the reference's order (threshold_level = 0, nothing pruned).
+    On such a file HierarchicalNSWSlim::searchKnn(q,k,tableint*) (hnswalg_slim.h:2030-2131) performs the same greedy
+    descent and the same level-0 beam as HierarchicalNSW::searchKnn (hnswalg.h:1378-1440), so its k-set, fp32 distances
+    and distance-evaluation count (minus the entry distance vanilla recomputes, hnswalg.h:347-351) must equal the
+    compiled reference's golden outputs;
+  * feed the product's and the oracle's Slim loaders a file that neither of them wrote (stale pointer bytes filled
+    with garbage, blobs present iff blobSize != 0 and total_neighbor != 0).
+
+Delete marks cannot be carried over: the Slim class reads the mark from byte 2 of total_neighbor (hnswalg_slim.h:1776-1781)
+while get_total_neighbor (:644) reads all four bytes, and convertFromHNSW (:1088) never sets it -- no valid Slim file holds a
+marked element.  Marked vanilla fixtures are therefore encoded with has_deleted_elements = 1 and unmarked elements.
+"""
+import struct
+
+import numpy as np
+
+VANILLA_HDR = "<6QiI3QdQ"   # offsetLevel0, max_elements, count, size_per_el, label_offset, offsetData, maxlevel, ep, maxM, maxM0, M, mult, efC
+SLIM_HDR = "<6Q2iI4Q?"      # count, size_per_el, label_offset, offsetTotalNeighbor, offsetData, offsetNeighbor, maxlevel, threshold_level,
+                            # enterpoint, maxM, maxM0, M, efC, has_deleted_elements   (93 bytes)
+
+
+def parse_vanilla(raw):
+    """Independent parse of a vanilla index file -> dict(header fields, per-node lists per level, labels, rows, marks)."""
+    (off0, max_el, count, spe, label_off, off_data, maxlevel, ep, maxM, maxM0, M, mult, efC) = struct.unpack_from(VANILLA_HDR, raw, 0)
+    pos = struct.calcsize(VANILLA_HDR)
+    dim = (spe - 4 - 4 * maxM0 - 8) // 4
+    assert spe == 4 + 4 * maxM0 + 4 * dim + 8
+    l0 = np.frombuffer(raw, np.uint8, count * spe, pos).reshape(count, spe)
+    pos += count * spe
+    cnt0 = l0[:, off0:off0 + 2].copy().view(np.uint16)[:, 0].astype(np.int64)
+    marks = (l0[:, off0 + 2] & 1).astype(np.uint8)
+    ids0 = l0[:, off0 + 4:off0 + 4 + 4 * maxM0].copy().view(np.uint32)
+    rows = l0[:, off_data:off_data + 4 * dim].copy().view(np.float32)
+    labels = l0[:, label_off:label_off + 8].copy().view(np.uint64)[:, 0]
+    per = 4 + 4 * maxM
+    lists = []
+    for i in range(count):
+        (sz,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        assert sz % per == 0
+        node = [ids0[i, :cnt0[i]].copy()]
+        for lv in range(sz // per):
+            (c,) = struct.unpack_from("<H", raw, pos + lv * per)
+            node.append(np.frombuffer(raw, np.uint32, c, pos + lv * per + 4).copy())
+        pos += sz
+        lists.append(node)
+    assert pos == len(raw)
+    return dict(count=count, dim=dim, maxlevel=maxlevel, enterpoint=ep, maxM=maxM, maxM0=maxM0, M=M, efC=efC, lists=lists, labels=labels,
+                rows=rows, marks=marks)
+
+
+def write_slim(g, threshold_level=0, has_deleted=None, garbage_seed=12345):
+    """Serialise dict(count, dim, maxlevel, enterpoint, maxM, maxM0, M, efC, lists[node][level] -> ids, labels, rows) as a Slim file."""
+    n, dim = g["count"], g["dim"]
+    spe = 24 + 4 * dim
+    if has_deleted is None:
+        has_deleted = bool(np.any(g.get("marks", np.zeros(1, np.uint8))))
+    out = [struct.pack(SLIM_HDR, n, spe, 8, 4, 24, 16, g["maxlevel"], threshold_level, g["enterpoint"], g["maxM"], g["maxM0"], g["M"],
+                       g["efC"], has_deleted)]
+    rng = np.random.default_rng(garbage_seed)
+    el = np.zeros((n, spe), np.uint8)
+    blobs = []
+    for i in range(n):
+        node = g["lists"][i]
+        level = len(node) - 1
+        total = int(sum(len(x) for x in node))
+        cum = np.cumsum([len(x) for x in node])[:level].astype(np.uint16)   # off[l] = end of the level-l slice, l < level
+        blob = cum.tobytes() + (np.concatenate(node).astype(np.uint32).tobytes() if total else b"")
+        assert len(blob) == 2 * level + 4 * total
+        blobs.append((blob, total))
+        el[i, 0:4] = np.frombuffer(struct.pack("<i", level), np.uint8)
+        el[i, 4:8] = np.frombuffer(struct.pack("<I", total), np.uint8)
+        el[i, 8:16] = np.frombuffer(struct.pack("<Q", int(g["labels"][i])), np.uint8)
+    el[:, 16:24] = rng.integers(1, 256, size=(n, 8), dtype=np.uint8)   # the 8 stale char* bytes saveIndex dumps: never zero here
+    el[:, 24:] = np.ascontiguousarray(g["rows"], np.float32).view(np.uint8).reshape(n, 4 * dim)
+    out.append(el.tobytes())
+    for blob, total in blobs:
+        out.append(struct.pack("<I", len(blob)))
+        if len(blob) and total:          # hnswalg_slim.h:745-748
+            out.append(blob)
+    return b"".join(out)
+
+
+def vanilla_to_slim_verbatim(raw, **kw):
+    return write_slim(parse_vanilla(raw), **kw)
+
+
+def parse_slim(raw, dim):
+    """Independent reader of a Slim file (consumes it to the last byte) -> per-node level, lists per level, labels, rows."""
+    hdr = struct.unpack_from(SLIM_HDR, raw, 0)
+    n, spe = hdr[0], hdr[1]
+    assert spe == 24 + 4 * dim and hdr[2:6] == (8, 4, 24, 16)
+    pos = struct.calcsize(SLIM_HDR)
+    el = np.frombuffer(raw, np.uint8, n * spe, pos).reshape(n, spe)
+    pos += n * spe
+    level = el[:, 0:4].copy().view(np.int32)[:, 0]
+    total = el[:, 4:8].copy().view(np.uint32)[:, 0]
+    lists = []
+    for i in range(n):
+        (sz,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        L, T = int(level[i]), int(total[i])
+        assert sz == 2 * L + 4 * T
+        if sz == 0 or T == 0:
+            lists.append([np.zeros(0, np.uint32) for _ in range(L + 1)])
+            continue
+        off = np.frombuffer(raw, np.uint16, L, pos).astype(np.int64)
+        ids = np.frombuffer(raw, np.uint32, T, pos + 2 * L)
+        pos += sz
+        bounds = [0] + list(off) + [T]
+        lists.append([ids[bounds[l]:bounds[l + 1]].copy() for l in range(L + 1)])
+    assert pos == len(raw)
+    return dict(count=n, dim=dim, maxlevel=hdr[6], threshold_level=hdr[7], enterpoint=hdr[8], maxM=hdr[9], maxM0=hdr[10], M=hdr[11],
+                efC=hdr[12], has_deleted=hdr[13], level=level, lists=lists, labels=el[:, 8:16].copy().view(np.uint64)[:, 0],
+                rows=el[:, 24:].copy().view(np.float32))

@@ -9,8 +9,11 @@
 //   * distance recipes + vanilla HierarchicalNSW search: pinned against the compiled reference
 //     (oracle/_ref/ref_hnsw, built from /root/reference/third_party/hnswlib as-is) through the
 //     fixtures in tests/golden/.
-//   * HierarchicalNSWSlim search / file format: PARITY UNPINNED by a compiled reference
-//     (hnswalg_slim.h needs folly, absent here); restated from source reading only.
+//   * HierarchicalNSWSlim (hnswalg_slim.h needs folly, absent here, so the class itself cannot be compiled): the
+//     search, the CHAL slice addressing and the Slim loader are CROSS-PINNED to the compiled vanilla reference's golden
+//     outputs through a verbatim vanilla -> Slim re-encoding of the reference-built graphs (oracle/chal_encode.py,
+//     tests/test_oracle_golden.py::test_slim_search_on_verbatim_encoding_matches_reference); convertFromHNSW's pruning
+//     is restated from source reading only.
 //
 // All file:line citations are relative to /root/reference/third_party/hnswlib/.
 #pragma once
@@ -493,6 +496,15 @@ inline SlimResult slim_search_core(const SlimIndex &ix, const float *q, size_t k
   return r;
 }
 
+// Level-0 entry of a query: the node the upper-layer greedy ends on (hnswalg_slim.h:2033-2078).
+inline uint32_t slim_entry(const SlimIndex &ix, const float *q) {
+  Counters c;
+  uint32_t cur = ix.enterpoint;
+  float curdist = dist(ix.metric, q, ix.vec(cur), ix.dim);
+  slim_upper(ix, q, cur, curdist, c);
+  return cur;
+}
+
 // searchKnn(q, k, tableint* result)  (hnswalg_slim.h:2030-2131): nth_element + label truncation.
 inline SlimResult slim_search_ids(const SlimIndex &ix, const float *q, size_t k, Scratch &s, uint32_t *out) {
   SlimResult r = slim_search_core(ix, q, k, s, /*mark_ep=*/false);
@@ -505,9 +517,11 @@ inline SlimResult slim_search_ids(const SlimIndex &ix, const float *q, size_t k,
 
 // searchKnn(q, k) -> priority_queue (hnswalg_slim.h:1907-2028).  Returned in pop order
 // (farthest first) as (dist,label).
+// mark_ep = false is NOT a reference overload: it is the cross-pin knob of tests/test_oracle_golden.py (the filter branch
+// of the beam against the compiled vanilla reference, which does not pre-mark its enter point).
 inline SlimResult slim_search_pq(const SlimIndex &ix, const float *q, size_t k, Scratch &s,
-                                 std::vector<std::pair<float, uint64_t>> &out) {
-  SlimResult r = slim_search_core(ix, q, k, s, /*mark_ep=*/true);
+                                 std::vector<std::pair<float, uint64_t>> &out, bool mark_ep = true) {
+  SlimResult r = slim_search_core(ix, q, k, s, mark_ep);
   std::vector<pairfi> t = r.top;
   while (t.size() > k) {                                             // :2019-2022
     std::pop_heap(t.begin(), t.end(), cmp_max());

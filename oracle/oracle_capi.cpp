@@ -8,6 +8,7 @@ using namespace hso;
 
 struct Handle {
   int kind;  // 0 vanilla, 1 slim
+  int mark_ep = -1;  // -1: as the overload does; 0 / 1: forced (cross-pin knob, see slim_search_pq)
   VanillaIndex v;
   SlimIndex s;
 };
@@ -35,6 +36,29 @@ void hso_set_filter(void *p, const uint8_t *allowed) {
   auto &dst = h->kind == 0 ? h->v.allowed : h->s.allowed;
   if (allowed) dst.assign(allowed, allowed + n);
   else dst.clear();
+}
+void hso_set_mark_ep(void *p, int v) { ((Handle *)p)->mark_ep = v; }
+// level-0 entry node of each query (Slim index)
+void hso_slim_entry(void *p, const float *q, size_t nq, uint32_t *out) {
+  auto *h = (Handle *)p;
+  for (size_t i = 0; i < nq; i++) out[i] = slim_entry(h->s, q + i * h->s.dim);
+}
+// SearchBuffer restatement driven by an op sequence: op[i] = 1 -> `if (!is_full(d)) insert(id, d)`, 0 -> `if (has_next()) pop()`.
+// ev[i] = 1/0 (inserted or not) resp. the popped id (0xFFFFFFFF when nothing to pop); final array -> out_id/out_d, returns size.
+size_t hso_pool_run(size_t cap, const uint8_t *op, const uint32_t *ids, const float *d, size_t n, uint32_t *ev, uint32_t *out_id,
+                    float *out_d) {
+  Pool pool(cap);
+  for (size_t i = 0; i < n; i++) {
+    if (op[i]) {
+      if (pool.is_full(d[i])) { ev[i] = 0; continue; }
+      pool.insert(ids[i], d[i]);
+      ev[i] = 1;
+    } else {
+      ev[i] = pool.has_next() ? pool.pop() : 0xFFFFFFFFu;
+    }
+  }
+  for (size_t i = 0; i < pool.size; i++) { out_id[i] = pool.d[i].second; out_d[i] = pool.d[i].first; }
+  return pool.size;
 }
 size_t hso_count(void *p) { auto *h = (Handle *)p; return h->kind == 0 ? h->v.count : h->s.count; }
 int hso_maxlevel(void *p) { auto *h = (Handle *)p; return h->kind == 0 ? h->v.maxlevel : h->s.maxlevel; }
@@ -83,7 +107,7 @@ int hso_search_pq(void *p, const float *q, size_t nq, size_t k, float *out_d, ui
     for (long i = 0; i < (long)nq; i++) {
       try {
         SlimResult r = h->kind == 0 ? vanilla_search_pq(h->v, q + i * dim, k, s, res)
-                                    : slim_search_pq(h->s, q + i * dim, k, s, res);
+                                    : slim_search_pq(h->s, q + i * dim, k, s, res, h->mark_ep != 0);
         out_cnt[i] = res.size();
         for (size_t j = 0; j < res.size(); j++) { out_d[i * k + j] = res[j].first; out_l[i * k + j] = res[j].second; }
         put_raw(r, raw_cap, raw_d, raw_i, raw_sz, counters, i);

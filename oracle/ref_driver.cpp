@@ -6,7 +6,8 @@
 // they lie (no copies, no stand-in headers) into oracle/_ref/ref_hnsw and is used to
 //   (1) pin the distance-function recipes (space_l2.h:25-54, space_ip.h:146-199),
 //   (2) build vanilla HNSW index files single-threaded (hnswalg.h:1248-1376, 748-779),
-//   (3) dump searchKnn results (hnswalg.h:1378-1440) + per-query distance-call counts
+//   (3) dump searchKnn results (hnswalg.h:1378-1440) + per-query distance-call counts,
+//   (4) dump BruteforceSearch::searchKnn results (bruteforce.h:106-135)
 // as golden fixtures under tests/golden/.
 //
 // NOT buildable here: hnswalg_slim.h / hnswalg_slimq.h (they include
@@ -140,13 +141,42 @@ static int cmd_markdel(int argc, char **argv) {
   return 0;
 }
 
+// bf <metric> <base.fvecs> <query.fvecs> <out.bin> <k>
+// hnswlib::BruteforceSearch (bruteforce.h): addPoint loop (label = row), searchKnn (:106-135) per query.
+// out.bin: u32 nq, u32 k, per query k x {f32 dist, u64 label} in priority_queue pop order (farthest first).
+static int cmd_bf(int argc, char **argv) {
+  if (argc < 7) return 2;
+  size_t n, d, nq, dq;
+  auto X = read_fvecs(argv[3], n, d);
+  auto Q = read_fvecs(argv[4], nq, dq);
+  if (d != dq) return 3;
+  auto *space = make_space(argv[2], d);
+  hnswlib::BruteforceSearch<float> bf(space, n);
+  for (size_t i = 0; i < n; i++) bf.addPoint(X.data() + i * d, i);
+  uint32_t k = atoi(argv[6]), nq32 = nq;
+  std::ofstream o(argv[5], std::ios::binary);
+  o.write((char *)&nq32, 4); o.write((char *)&k, 4);
+  for (size_t i = 0; i < nq; i++) {
+    auto res = bf.searchKnn(Q.data() + i * d, k);
+    if (res.size() != k) return 4;
+    while (!res.empty()) {
+      float dist = res.top().first;
+      uint64_t label = res.top().second;
+      o.write((char *)&dist, 4); o.write((char *)&label, 8);
+      res.pop();
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
-  if (argc < 2) { fprintf(stderr, "usage: ref_hnsw dist|build|search ...\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: ref_hnsw dist|build|search|bf ...\n"); return 2; }
   std::string c = argv[1];
   if (c == "dist") return cmd_dist(argc, argv);
   if (c == "build") return cmd_build(argc, argv);
   if (c == "search") return cmd_search(argc, argv);
   if (c == "markdel") return cmd_markdel(argc, argv);
+  if (c == "bf") return cmd_bf(argc, argv);
   if (c == "searchf") {  // searchf <mod> <rem> <metric> <index> <query.fvecs> <out.bin> <k> <ef>...
     if (argc < 10) return 2;
     g_filter = new ModFilter(atoi(argv[2]), atoi(argv[3]));

@@ -10,6 +10,7 @@
 //                                                        rabitqlib/utils/warmup_space.hpp:8-102
 //   data   : one_bit_compact_code (1-bit code + f_add, f_rescale, f_error)
 //                                                        rabitqlib/quantization/rabitq_impl.hpp:75-187
+//   buffer : rabitqlib::buffer::SearchBuffer            rabitqlib/utils/buffer.hpp:16-100
 // All arrays are raw little-endian binaries; shapes are passed on the command line (tests/golden/make_golden.py).
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@
 #include "rabitqlib/index/estimator.hpp"
 #include "rabitqlib/index/query.hpp"
 #include "rabitqlib/quantization/rabitq.hpp"
+#include "rabitqlib/utils/buffer.hpp"
 #include "rabitqlib/utils/rotator.hpp"
 
 template <typename T>
@@ -104,6 +106,39 @@ int main(int argc, char **argv) {
     printf("%.17g\n", cfg.t_const);
     return 0;
   }
-  fprintf(stderr, "usage: ref_rabitq rotate|data|query|tconst ...\n");
+  if (c == "buffer") {
+    // buffer <cap> <n> <op.u8> <ids.u32> <dist.f32> <out_ev.u32> <out_final.bin>
+    // rabitqlib::buffer::SearchBuffer (rabitqlib/utils/buffer.hpp:16-100; hnswalg_slimq.h:80-151 is the same class with the
+    // is_full test hoisted to the caller) driven by an op sequence: 1 = insert (no-op when is_full(dist)), 0 = pop if has_next.
+    // out_ev[i]: 1/0 inserted or not, resp. the popped id (0xFFFFFFFF when nothing to pop); out_final: u32 size, then size x {u32 id, f32 dist}.
+    size_t cap = atoi(argv[2]), n = atoi(argv[3]);
+    auto op = rd<uint8_t>(argv[4], n);
+    auto ids = rd<uint32_t>(argv[5], n);
+    auto ds = rd<float>(argv[6], n);
+    rabitqlib::buffer::SearchBuffer<float> buf(cap);
+    std::vector<uint32_t> ev(n);
+    size_t size = 0;
+    for (size_t i = 0; i < n; i++) {
+      if (op[i]) {
+        if (buf.is_full(ds[i])) { ev[i] = 0; continue; }
+        buf.insert(ids[i], ds[i]);
+        ev[i] = 1;
+        if (size < cap) size++;
+      } else {
+        ev[i] = buf.has_next() ? buf.pop() : 0xFFFFFFFFu;
+      }
+    }
+    wr(argv[7], ev);
+    std::ofstream o(argv[8], std::ios::binary);
+    uint32_t sz = (uint32_t)size;
+    o.write((char *)&sz, 4);
+    for (size_t i = 0; i < size; i++) {
+      uint32_t id = buf.data()[i].id;
+      float dd = buf.data()[i].distance;
+      o.write((char *)&id, 4); o.write((char *)&dd, 4);
+    }
+    return 0;
+  }
+  fprintf(stderr, "usage: ref_rabitq rotate|data|query|tconst|buffer ...\n");
   return 2;
 }

@@ -145,9 +145,69 @@ def rabitq_fixture(tmp):
     np.savez_compressed(os.path.join(GOLDEN, "rabitq_ref.npz"), **out)
 
 
+def bruteforce_fixture(tmp):
+    """hnswlib::BruteforceSearch::searchKnn (bruteforce.h:106-135) of the compiled reference: continuous L2, tie-heavy integer
+    L2 (ties across the k-th boundary) and inner product."""
+    out = {}
+    cases = {"l2_cont": ("l2", mixture(3000, 24, 201), mixture(40, 24, 202)),
+             "l2_int": ("l2", mixture(3000, 8, 203, lo=2, hi=8, sigma=2.0, integer=True), mixture(40, 8, 204, lo=2, hi=8, sigma=2.0, integer=True)),
+             "ip": ("ip", mixture(2000, 48, 205, lo=-1, hi=1, sigma=0.5), mixture(40, 48, 206, lo=-1, hi=1, sigma=0.5))}
+    for name, (metric, base, q) in cases.items():
+        fb, fq, fo = (os.path.join(tmp, f"bf_{x}.bin") for x in "bqo")
+        write_fvecs(fb, base)
+        write_fvecs(fq, q)
+        for k in (1, 10, 33):
+            run("bf", metric, fb, fq, fo, k)
+            raw = open(fo, "rb").read()
+            nq, kk = np.frombuffer(raw, np.uint32, 2)
+            rec = np.frombuffer(raw, np.dtype([("d", "<f4"), ("l", "<u8")]), nq * kk, 8).reshape(nq, kk)
+            out[f"{name}_k{k}_dists"] = rec["d"].copy()
+            out[f"{name}_k{k}_labels"] = rec["l"].copy()
+        out[f"{name}_base"] = base
+        out[f"{name}_queries"] = q
+    np.savez_compressed(os.path.join(GOLDEN, "bruteforce_ref.npz"), **out)
+
+
+def searchbuffer_fixture(tmp):
+    """Event order of the compiled rabitqlib::buffer::SearchBuffer (rabitqlib/utils/buffer.hpp:16-100) under random
+    insert / pop sequences, continuous and tie-heavy distances, several capacities."""
+    RQ = os.path.join(ROOT, "oracle", "_ref", "ref_rabitq")
+    rng = np.random.default_rng(4242)
+    out = {}
+    for ci, (cap, n, ties) in enumerate(((8, 400, True), (32, 1500, True), (64, 3000, False), (200, 6000, True), (1, 50, True))):
+        op = (rng.random(n) < 0.72).astype(np.uint8)
+        op[:3] = 1
+        ids = rng.integers(0, 1 << 20, n).astype(np.uint32)
+        d = rng.integers(0, 40, n).astype(np.float32) if ties else rng.random(n).astype(np.float32)
+        # drift towards smaller distances, like a search that converges
+        d = (d * np.linspace(1.5, 0.6, n)).astype(np.float32) if not ties else d
+        f = {k: os.path.join(tmp, f"sb_{k}.bin") for k in ("op", "ids", "d", "ev", "fin")}
+        op.tofile(f["op"]); ids.tofile(f["ids"]); d.tofile(f["d"])
+        subprocess.check_call([RQ, "buffer", str(cap), str(n), f["op"], f["ids"], f["d"], f["ev"], f["fin"]])
+        fin = open(f["fin"], "rb").read()
+        sz = int(np.frombuffer(fin, np.uint32, 1)[0])
+        rec = np.frombuffer(fin, np.dtype([("id", "<u4"), ("d", "<f4")]), sz, 4)
+        p = f"c{ci}_"
+        out.update({p + "cap": np.array(cap), p + "op": op, p + "ids": ids, p + "d": d, p + "ev": np.fromfile(f["ev"], np.uint32),
+                    p + "final_id": rec["id"].copy(), p + "final_d": rec["d"].copy()})
+    out["n_cases"] = np.array(5)
+    np.savez_compressed(os.path.join(GOLDEN, "searchbuffer_ref.npz"), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    only = set(sys.argv[1:])   # e.g. `make_golden.py bf buffer`: (re)generate just these, leaving the other files byte-stable
+    if only:
+        with tempfile.TemporaryDirectory() as tmp:
+            if "bf" in only:
+                bruteforce_fixture(tmp)
+            if "buffer" in only:
+                searchbuffer_fixture(tmp)
+        print("golden fixtures written:", sorted(only))
+        return
     with tempfile.TemporaryDirectory() as tmp:
+        bruteforce_fixture(tmp)
+        searchbuffer_fixture(tmp)
         dist_fixture(tmp)
         # continuous (tie-free) L2, d=32
         index_fixture(tmp, "l2_cont_d32", "l2", mixture(2000, 32, 1), mixture(100, 32, 2), 8, 100, [10, 32, 64])

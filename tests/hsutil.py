@@ -74,6 +74,14 @@ def headline_data(n, d, seed):
     return sift_like(n, d, seed, n_clusters=4096, rank=12, sigma_sub=40.0, sigma_iso=4.0)
 
 
+def load_chal_encode():
+    """oracle/chal_encode.py (test infrastructure: the independent Python writer / reader of the Slim file format)."""
+    spec = importlib.util.spec_from_file_location("chal_encode", os.path.join(ROOT, "oracle", "chal_encode.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load_product():
     """Import the product package (directory name has a hyphen, so load it by path)."""
     name = "hnsw_slim_amd"
@@ -101,6 +109,10 @@ class Oracle:
         L.hso_free.argtypes = [ctypes.c_void_p]
         L.hso_set_ef.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         L.hso_set_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.hso_set_mark_ep.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.hso_slim_entry.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.hso_pool_run.restype = ctypes.c_size_t
+        L.hso_pool_run.argtypes = [ctypes.c_size_t] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 3
         L.hso_count.restype = ctypes.c_size_t
         L.hso_count.argtypes = [ctypes.c_void_p]
         L.hso_maxlevel.argtypes = [ctypes.c_void_p]
@@ -150,6 +162,14 @@ class Oracle:
         self.L.hso_rq_est(codes.shape[1] * 64, metric, a[0].ctypes.data, a[1].ctypes.data, nd, a[2].ctypes.data, a[3].ctypes.data,
                           a[4].ctypes.data, nq, out.ctypes.data)
         return out
+
+    def pool_run(self, cap, op, ids, d):
+        """SearchBuffer restatement under an op sequence -> (events, final ids, final dists)."""
+        op, ids, d = np.ascontiguousarray(op, np.uint8), np.ascontiguousarray(ids, np.uint32), np.ascontiguousarray(d, np.float32)
+        ev = np.empty(len(op), np.uint32)
+        oi, od = np.empty(cap + 1, np.uint32), np.empty(cap + 1, np.float32)
+        sz = self.L.hso_pool_run(cap, op.ctypes.data, ids.ctypes.data, d.ctypes.data, len(op), ev.ctypes.data, oi.ctypes.data, od.ctypes.data)
+        return ev, oi[:sz], od[:sz]
 
     def load_slimq(self, path):
         h = self.L.hso_slimq_load(path.encode())
@@ -251,6 +271,17 @@ class OracleIndex:
     def set_ef(self, ef):
         self.ef = ef
         self.o.L.hso_set_ef(self.h, ef)
+
+    def set_mark_ep(self, v):
+        """-1: as the overload does; 0 / 1: force (cross-pin knob of the pq overloads, see oracle/hs_oracle.hpp)."""
+        self.o.L.hso_set_mark_ep(self.h, int(v))
+
+    def entry(self, q):
+        """Level-0 entry node of each query (Slim index)."""
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.empty(q.shape[0], np.uint32)
+        self.o.L.hso_slim_entry(self.h, q.ctypes.data, q.shape[0], out.ctypes.data)
+        return out
 
     def set_filter(self, allowed):
         """allowed: uint8[n] by internal id, or None."""

@@ -84,3 +84,18 @@ def test_bruteforce_cpp_facade(env, tmp_path):
     labels = (1000 + 3 * np.arange(600)).astype(np.uint64)
     el, ed = _expect(O, 0, base, q, 10, labels)
     assert np.array_equal(rec["l"][:, ::-1], el) and np.array_equal(rec["d"][:, ::-1].copy().view(np.uint32), ed.view(np.uint32))
+
+
+def test_brute_force_vs_compiled_bruteforce(env):
+    """hs_brute_force against outputs of the COMPILED hnswlib::BruteforceSearch::searchKnn (bruteforce.h:106-135,
+    tests/golden/bruteforce_ref.npz): labels and fp32 distances bit for bit, ties across the k-th boundary included."""
+    import os
+    from hsutil import GOLDEN
+    P, _ = env
+    g = np.load(os.path.join(GOLDEN, "bruteforce_ref.npz"))
+    for name, metric in (("l2_cont", 0), ("l2_int", 0), ("ip", 1)):
+        for k in (1, 10, 33):
+            gl, gd, gc = P.brute_force(g[f"{name}_base"], g[f"{name}_queries"], k, metric)
+            assert np.all(gc == k)
+            assert np.array_equal(gl, g[f"{name}_k{k}_labels"][:, ::-1]), f"{name} k={k}"   # pop order is farthest first
+            assert gd.tobytes() == np.ascontiguousarray(g[f"{name}_k{k}_dists"][:, ::-1]).tobytes(), f"{name} k={k}"

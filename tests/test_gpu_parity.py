@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from hsutil import GOLDEN, load_product, mixture
+from hsutil import GOLDEN, load_chal_encode, load_product, mixture
 
 pytestmark = pytest.mark.gpu
 L2, IP = 0, 1
@@ -59,6 +59,72 @@ def test_vanilla_vs_compiled_reference(hs, oracle, name, metric, dim):
             assert np.array_equal(raw["raw_i"][i, :n], o["raw_i"][i, :n])
             assert raw["raw_d"][i, :n].tobytes() == o["raw_d"][i, :n].tobytes()
         assert np.array_equal(raw["stats"][:, :3], o["counters"][:, :3])
+
+
+# ---- HierarchicalNSWSlim on the GPU cross-pinned to the compiled vanilla reference (see tests/test_oracle_golden.py) -----
+def _verbatim(tmp_path, name, **kw):
+    ce = load_chal_encode()
+    sp = tmp_path / f"{name}.verbatim.slim"
+    sp.write_bytes(ce.vanilla_to_slim_verbatim(open(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "rb").read(), **kw))
+    return str(sp)
+
+
+@pytest.mark.parametrize("name,metric,dim", [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48),
+                                             ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21), ("l2_cont_d10", L2, 10),
+                                             ("ip_d20", IP, 20), ("ip_d21", IP, 21), ("ip_d10", IP, 10)])
+def test_slim_verbatim_encoding_vs_compiled_reference(hs, tmp_path, name, metric, dim):
+    """A reference-built graph re-encoded verbatim as a Slim file (written by Python, garbage in the stale pointer bytes):
+    hs_search_batch in HS_MODE_SLIM_IDS (= HierarchicalNSWSlim::searchKnn(q,k,tableint*), hnswalg_slim.h:2030-2131) must give
+    the compiled vanilla reference's k-set, fp32 distances and distance-call count (minus the entry distance only vanilla
+    recomputes, hnswalg.h:347-351) -- strict kernel and fast kernel.  No oracle involved."""
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    ix = hs.Index(_verbatim(tmp_path, name), hs.HS_KIND_SLIM, dim, metric)
+    k = int(g["k"])
+    for exact in (True, False):
+        ix.set_exact_order(exact)
+        for ef in g["efs"]:
+            ef = int(ef)
+            ix.set_ef(ef)
+            r = ix.search_ids(g["queries"], k, want_dists=True, want_stats=True)
+            assert np.array_equal(r["stats"][:, 0], g[f"ef{ef}_calls"] - 1), f"{name} ef={ef}: distance evaluations differ"
+            for i in range(len(r["labels"])):
+                got = sorted(zip(r["dists"][i].view(np.uint32).tolist(), r["labels"][i].tolist()))
+                want = sorted(zip(g[f"ef{ef}_dists"][i].view(np.uint32).tolist(), g[f"ef{ef}_labels"][i].tolist()))
+                if name != "l2_int_d16":
+                    assert got == want, f"{name} ef={ef} exact={exact} query {i}"
+                else:   # ties across the k-th boundary: nth_element and pop_heap pick by layout; the distance multiset is unique
+                    assert [x[0] for x in got] == [x[0] for x in want], f"{name} ef={ef} exact={exact} query {i}"
+
+
+def test_slim_filtered_verbatim_vs_compiled_reference(hs, oracle, tmp_path):
+    """searchKnn(q,k,isIdAllowed) on the verbatim Slim file against the compiled vanilla reference's filtered search, on the
+    queries where the two classes' different entry handling cannot matter: the level-0 entry passes the filter (Slim always
+    seeds the result heap with it, hnswalg_slim.h:2100; vanilla only if allowed, hnswalg.h:347-362) and pre-marking the global
+    enter point (hnswalg_slim.h:1796) changes nothing (checked on the oracle, with and without the pre-mark)."""
+    name, dim = "l2_cont_d32", 32
+    g = np.load(os.path.join(GOLDEN, f"{name}_filter.npz"))
+    sp = _verbatim(tmp_path, name)
+    ix = hs.Index(sp, hs.HS_KIND_SLIM, dim)
+    ox = oracle.load(sp, "slim", L2, dim)
+    allowed = (ix.labels() % int(g["mod"]) != int(g["rem"])).astype(np.uint8)
+    ox.set_filter(allowed)
+    entry_ok = allowed[ox.entry(g["queries"])] == 1
+    k = int(g["k"])
+    compared = 0
+    for ef in g["efs"]:
+        ef = int(ef)
+        ix.set_ef(ef); ox.set_ef(ef)
+        ox.set_mark_ep(1); a = ox.search_pq(g["queries"], k)
+        ox.set_mark_ep(0); b = ox.search_pq(g["queries"], k)
+        same = np.all(a["labels"] == b["labels"], axis=1) & np.all(a["counters"][:, :3] == b["counters"][:, :3], axis=1)
+        ok = entry_ok & same
+        r = ix.search_filtered(g["queries"], k, allowed, want_stats=True)
+        assert np.array_equal(r["cnt"][ok], g[f"ef{ef}_cnt"][ok])
+        got, want = _pq_sorted(r["dists"], r["labels"], r["cnt"]), _pq_sorted(g[f"ef{ef}_dists"], g[f"ef{ef}_labels"], g[f"ef{ef}_cnt"])
+        assert all(got[i] == want[i] for i in np.nonzero(ok)[0]), f"ef={ef}"
+        assert np.array_equal(r["stats"][ok, 0], g[f"ef{ef}_calls"][ok] - 1)
+        compared += int(ok.sum())
+    assert compared >= 0.5 * len(entry_ok) * len(g["efs"])
 
 
 def _slim_case(hs, oracle, tmp_path, base, queries, dim, metric, M, efC, efs, k=10, threads=8, fast=True, **slim_kw):

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from hsutil import GOLDEN
+from hsutil import GOLDEN, load_chal_encode
 
 L2, IP = 0, 1
 
@@ -86,6 +86,126 @@ def test_vanilla_filtered_search_matches_reference(oracle, name, dim):
         assert np.array_equal(r["labels"], g[f"ef{ef}_labels"])
         assert r["dists"].tobytes() == g[f"ef{ef}_dists"].tobytes()
         assert np.array_equal(r["counters"][:, 0], g[f"ef{ef}_calls"])
+
+
+# ---- HierarchicalNSWSlim cross-pinned to the compiled vanilla reference --------------------------------------------------
+# hnswalg_slim.h itself cannot be compiled here (folly).  A graph the compiled reference built, re-encoded VERBATIM as a Slim
+# file (oracle/chal_encode.py: every list kept, reference order, threshold_level 0), makes HierarchicalNSWSlim::searchKnn
+# (hnswalg_slim.h:2030-2131) walk exactly what HierarchicalNSW::searchKnn (hnswalg.h:1378-1440) walks: same descent, same
+# level-0 beam.  So the Slim restatement -- loader, CHAL slice addressing, beam, nth_element finish -- must reproduce the
+# compiled reference's golden k-set, fp32 distances and distance-call count (minus the entry distance that only the vanilla
+# searchBaseLayerST recomputes, hnswalg.h:347-351).
+PLAIN = [("l2_cont_d32", L2, 32), ("l2_int_d16", L2, 16), ("ip_d48", IP, 48), ("l2_cont_d20", L2, 20), ("l2_cont_d21", L2, 21),
+         ("l2_cont_d10", L2, 10), ("ip_d20", IP, 20), ("ip_d21", IP, 21), ("ip_d10", IP, 10)]
+
+
+def verbatim_slim_file(tmp_path, name, **kw):
+    ce = load_chal_encode()
+    raw = open(os.path.join(GOLDEN, f"{name}.hnsw.bin"), "rb").read()
+    sp = tmp_path / f"{name}.verbatim.slim"
+    sp.write_bytes(ce.vanilla_to_slim_verbatim(raw, **kw))
+    return str(sp)
+
+
+def check_ids_against_golden(g, ef, labels, raw_d, raw_i, raw_sz, n_dist, tie_free):
+    """labels: nq x k of searchKnn(q,k,tableint*); raw_*: the top_candidates arrays (id -> distance); golden: pq pop order."""
+    k = labels.shape[1]
+    for i in range(labels.shape[0]):
+        assert g[f"ef{ef}_cnt"][i] == k
+        d_of = dict(zip(raw_i[i, :raw_sz[i]].tolist(), raw_d[i, :raw_sz[i]].view(np.uint32).tolist()))
+        got = sorted((d_of[int(l)], int(l)) for l in labels[i])   # golden indexes: label == internal id
+        want = sorted(zip(g[f"ef{ef}_dists"][i].view(np.uint32).tolist(), g[f"ef{ef}_labels"][i].tolist()))
+        if tie_free:
+            assert got == want, f"ef={ef} query {i}"
+        else:   # equal distances across the k-th boundary: the two classes pick by heap layout; the distance multiset is unique
+            assert [x[0] for x in got] == [x[0] for x in want], f"ef={ef} query {i}"
+    assert np.array_equal(n_dist, g[f"ef{ef}_calls"] - 1), "distance evaluations differ from the compiled reference"
+
+
+@pytest.mark.parametrize("name,metric,dim", PLAIN)
+def test_slim_search_on_verbatim_encoding_matches_reference(oracle, tmp_path, name, metric, dim):
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    ix = oracle.load(verbatim_slim_file(tmp_path, name), "slim", metric, dim)
+    k = int(g["k"])
+    for ef in g["efs"]:
+        ef = int(ef)
+        ix.set_ef(ef)
+        r = ix.search_ids(g["queries"], k)
+        check_ids_against_golden(g, ef, r["labels"], r["raw_d"], r["raw_i"], r["raw_sz"], r["counters"][:, 0], tie_free=name != "l2_int_d16")
+
+
+def test_slim_filter_branch_on_verbatim_encoding_matches_reference(oracle, tmp_path):
+    """searchKnn(q,k,isIdAllowed): the !bare_bone beam with a filter (hnswalg_slim.h:462-618 as reached from :1783-1905)
+    against the compiled vanilla reference's filtered search.  The two classes treat the ENTRY differently -- Slim pre-marks
+    the global enter point (:1796) and always seeds the result heap with the level-0 entry (:2100), vanilla does neither
+    (hnswalg.h:347-362) -- so the comparison runs the restatement without the pre-mark and on the queries whose level-0
+    entry passes the filter; there the k-set, distances and distance-call counts must be the reference's."""
+    name, dim = "l2_cont_d32", 32
+    g = np.load(os.path.join(GOLDEN, f"{name}_filter.npz"))
+    ix = oracle.load(verbatim_slim_file(tmp_path, name), "slim", L2, dim)
+    allowed = (np.arange(ix.count) % int(g["mod"]) != int(g["rem"])).astype(np.uint8)
+    ix.set_filter(allowed)
+    ix.set_mark_ep(0)
+    ok = allowed[ix.entry(g["queries"])] == 1
+    assert ok.sum() >= 0.5 * len(ok)
+    k = int(g["k"])
+    for ef in g["efs"]:
+        ef = int(ef)
+        ix.set_ef(ef)
+        r = ix.search_pq(g["queries"], k)
+        assert np.array_equal(r["cnt"][ok], g[f"ef{ef}_cnt"][ok])
+        assert np.array_equal(r["labels"][ok], g[f"ef{ef}_labels"][ok])
+        assert r["dists"][ok].tobytes() == g[f"ef{ef}_dists"][ok].tobytes()
+        assert np.array_equal(r["counters"][ok, 0], g[f"ef{ef}_calls"][ok] - 1)
+
+
+def test_python_written_slim_file_round_trips(oracle, tmp_path):
+    """The Slim loader restatement on a file this repository's C++ did not write (garbage in the 8 stale pointer bytes of
+    every element, hnswalg_slim.h:127-131; blobs present iff blobSize != 0 and total_neighbor != 0, :745-748), and the
+    independent Python reader consuming it to the last byte."""
+    ce = load_chal_encode()
+    raw = open(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), "rb").read()
+    v = ce.parse_vanilla(raw)
+    a, b = ce.write_slim(v, garbage_seed=1), ce.write_slim(v, garbage_seed=2)
+    assert a != b and len(a) == len(b)
+    s = ce.parse_slim(a, 32)
+    assert s["count"] == v["count"] and all(len(x) == len(y) and all(np.array_equal(p, q) for p, q in zip(x, y))
+                                            for x, y in zip(s["lists"], v["lists"]))
+    outs = []
+    for i, blob in enumerate((a, b)):
+        f = tmp_path / f"g{i}.slim"
+        f.write_bytes(blob)
+        ix = oracle.load(str(f), "slim", L2, 32)
+        ix.set_ef(40)
+        outs.append(ix.search_ids(np.load(os.path.join(GOLDEN, "l2_cont_d32.npz"))["queries"], 10)["labels"])
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_brute_force_matches_compiled_bruteforce(oracle):
+    """oracle brute_force against hnswlib::BruteforceSearch::searchKnn (bruteforce.h:106-135) of the compiled reference."""
+    g = np.load(os.path.join(GOLDEN, "bruteforce_ref.npz"))
+    for name, metric in (("l2_cont", L2), ("l2_int", L2), ("ip", IP)):
+        base, q = g[f"{name}_base"], g[f"{name}_queries"]
+        for k in (1, 10, 33):
+            ids = oracle.brute_force(metric, base, q, k)
+            want_l = g[f"{name}_k{k}_labels"][:, ::-1]    # pop order is farthest first
+            want_d = g[f"{name}_k{k}_dists"][:, ::-1]
+            got_d = np.stack([oracle.dist(metric, np.repeat(q[i:i + 1], k, 0), base[ids[i]]) for i in range(len(q))])
+            assert got_d.tobytes() == np.ascontiguousarray(want_d).tobytes(), f"{name} k={k}"
+            # the reference keeps the k smallest (dist, label) pairs: with label == row that is the oracle's (dist, id) order
+            assert np.array_equal(ids, want_l), f"{name} k={k}"
+
+
+def test_searchbuffer_matches_compiled_rabitqlib(oracle):
+    """SearchBuffer restatement (hnswalg_slimq.h:80-151) against the compiled rabitqlib::buffer::SearchBuffer
+    (rabitqlib/utils/buffer.hpp:16-100): which inserts land, every popped id in order, the final array."""
+    g = np.load(os.path.join(GOLDEN, "searchbuffer_ref.npz"))
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}_"
+        ev, fi, fd = oracle.pool_run(int(g[p + "cap"]), g[p + "op"], g[p + "ids"], g[p + "d"])
+        assert np.array_equal(ev, g[p + "ev"]), f"case {c}: event sequence differs"
+        assert np.array_equal(fi, g[p + "final_id"]) and fd.tobytes() == g[p + "final_d"].tobytes()
+        assert (g[p + "op"] == 0).sum() > 10 and (ev[g[p + "op"] == 1] == 0).sum() > 0
 
 
 # ---- RaBitQ pieces of the SlimQ oracle against the compiled rabitqlib ------------------------------------------
