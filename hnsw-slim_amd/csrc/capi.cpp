@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -121,6 +122,7 @@ static uint32_t next_pow2(uint32_t v) {
 
 struct Shape {
   uint32_t ef, cand_cap, cand_cap_fast, hash_slots;
+  uint32_t g_cand_cap, g_hash_slots;    // group kernel (four queries per wavefront): per-query LDS shares
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
@@ -145,6 +147,34 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const uint32_t want = (uint32_t)((450 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash) / 0.75);
   s.hash_slots = ix->user_hash_slots ? (ix->user_hash_slots + 63) / 64 * 64 : (want + 63) / 64 * 64;
   const uint32_t dim = (uint32_t)ix->info.dim;
+  // Group kernel: LDS is what bounds the queries resident per CU, so the shares cover most queries (candidate heap: ~p99 of
+  // the peak size, visited set: ~p90 of the distance evaluations, measured on the 1M SIFT-like bench index for ef 32..256)
+  // and the rest continue in their tier-2 regions; then both are trimmed by up to 12 % if that admits one more wavefront per CU.
+  {
+    uint32_t gc = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((2.5 * ef + 130) * (1u << ix->grow_cand));
+    uint32_t gh = ix->user_hash_slots ? ix->user_hash_slots : (uint32_t)((520 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash) / 0.875);
+    gc = std::max<uint32_t>((gc + 1) & ~1u, 16);
+    gh = std::max<uint32_t>((gh + 3) & ~3u, std::max<uint32_t>(64, (uint32_t)(2 * (ef + 1) + 3) & ~3u));   // replay heap lives there
+    const bool qr = group_q_in_regs(ix->info.metric, dim);
+    if (!ix->user_cand_cap && !ix->user_hash_slots) {
+      const size_t per_wave = group_lds_bytes(dim, gc, gh, qr);
+      const size_t waves = per_wave ? kLdsPerCU / per_wave : 0;
+      if (waves >= 1 && waves < 8) {
+        const uint32_t gc2 = std::max<uint32_t>(((uint32_t)(gc * 0.88) + 1) & ~1u, 16), gh2 = std::max<uint32_t>(((uint32_t)(gh * 0.88) + 3) & ~3u, (uint32_t)(2 * (ef + 1) + 3) & ~3u);
+        if (group_lds_bytes(dim, gc2, gh2, qr) * (waves + 1) <= kLdsPerCU) {
+          // largest shares that still fit waves + 1 wavefronts
+          uint32_t c = gc, h = gh;
+          while (group_lds_bytes(dim, c, h, qr) * (waves + 1) > kLdsPerCU) {
+            if (h > gh2) h -= 4;
+            if (c > gc2) c -= 2;
+          }
+          gc = c; gh = h;
+        }
+      }
+    }
+    s.g_cand_cap = gc;
+    s.g_hash_slots = gh;
+  }
   // shrink the first-pass shape if it does not fit one CU at all
   while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.hash_slots > 256) s.hash_slots >>= 1;
   while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.cand_cap > 128) s.cand_cap = (s.cand_cap / 2 + 1) & ~1u;
@@ -435,9 +465,12 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   hs_index::StreamWs *w = ix->stream_ws(stream);
   HIP_TRY(w->status.ensure(nq));
   HIP_TRY(w->spill.ensure(nq * (size_t)kSpillStride));
-  HIP_TRY(w->counters.ensure(12));
+  HIP_TRY(w->counters.ensure(48));
   // (status needs no clearing: pass 0 takes every query and writes each one's final status)
-  if (first_group) HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));
+  // counters[0..12): per-pass overflow / hazard counts (accumulate over the launch groups of one call); [12]: the group
+  // kernel's query queue head (per launch group)
+  if (first_group) HIP_TRY(hipMemsetAsync(w->counters.p, 0, 48 * sizeof(uint32_t), stream));
+  else HIP_TRY(hipMemsetAsync(w->counters.p + 12, 0, sizeof(uint32_t), stream));
   w->last_nq = nq_total;
   SearchArgs a{};
   a.queries = d_q; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.ef = sh.ef;
@@ -449,12 +482,32 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
                     fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, sh.hash_slots) <= kLdsPerCU;
-  if (fast) a.cand_cap = sh.cand_cap_fast;
-  // pass 0: every query, one wavefront each
-  a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p; a.pass_id = 0;
-  HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
+  static const bool no_group = getenv("HS_NO_GROUP") != nullptr;   // diagnostic knob: keep the one-query-per-wave fast kernel
+  const bool group = !no_group && !ix->exact_order && !raw && group_supported(ix->dev, sh.ef, (uint32_t)k) &&
+                     group_lds_bytes((uint32_t)ix->info.dim, sh.g_cand_cap, sh.g_hash_slots, group_q_in_regs(ix->info.metric, (uint32_t)ix->info.dim)) <= kLdsPerCU;
+  a.queue = w->counters.p + 12;
+  a.counters = w->counters.p; a.pass_id = 0;
+  if (group) {
+    // pass 0: the group kernel (four queries per wavefront, persistent grid) answers every query; one whose scratch runs
+    // out even in its tier-2 regions is left ST_OVERFLOW for the one-query-per-wave kernels below
+    a.cand_cap = sh.g_cand_cap; a.hash_slots = sh.g_hash_slots;
+    a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
+    HIP_TRY(launch_group(ix->dev, a, stream));
+    a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots;
+    if (fast) {
+      a.cand_cap = sh.cand_cap_fast;
+      a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.pass_id = 3;
+      HIP_TRY(launch_fast(ix->dev, a, stream));
+      a.cand_cap = sh.cand_cap;
+    }
+  } else {
+    if (fast) a.cand_cap = sh.cand_cap_fast;
+    // pass 0: every query, one wavefront each
+    a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
+    HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
+  }
   // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
-  if (fast) {
+  if (fast || group) {
     a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
     a.counters = w->counters.p + 4; a.pass_id = 1;
     HIP_TRY(launch_strict(ix->dev, a, stream));
@@ -495,6 +548,17 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   if (!w->counters.p) return HS_OK;  // nothing was launched on this stream
   HIP_TRY(hipMemcpyAsync(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (getenv("HS_GPROF") && w->counters.n >= 48) {   // diagnostic build (make gprof): per-phase shader clocks of the group kernel
+    unsigned long long g[16];
+    HIP_TRY(hipMemcpy(g, w->counters.p + 16, sizeof(g), hipMemcpyDeviceToHost));
+    static const char *nm[10] = {"refill", "push", "pop", "tile-wait", "ids+visited", "distances", "post", "accept", "next+request", "finish"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 10; i++) tot += g[i];
+    if (tot) {
+      fprintf(stderr, "[hs gprof] wave-rounds %llu  push-iters %llu  accept-iters %llu  dist-passes %llu  finish-events %llu  cycles/round %.0f\n", g[10], g[11], g[12], g[13], g[14], (double)tot / (double)std::max(1ull, g[10]));
+      for (int i = 0; i < 10; i++) fprintf(stderr, "[hs gprof]   %-14s %6.1f %%  %8.0f cycles/round\n", nm[i], 100.0 * g[i] / tot, (double)g[i] / (double)std::max(1ull, g[10]));
+    }
+  }
   // learn the scratch sizes from the data: if more than 1% of a batch overflowed in the first passes,
   // later batches start with twice the visited-set slots / candidate capacity.
   const size_t nq = std::max<size_t>(w->last_nq, 1);

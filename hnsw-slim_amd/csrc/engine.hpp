@@ -52,6 +52,7 @@ struct SearchArgs {
   uint32_t *status;      // nq
   uint32_t *counters;    // [0] visited-set overflows, [1] candidate-heap overflows, [2] tie hazards, [3] tier-2 spills (this pass)
   uint32_t pass_id;
+  uint32_t *queue;       // group kernel: device-wide query counter (zeroed per launch group)
 };
 
 // Bytes of dynamic LDS one query (one wavefront) needs.
@@ -64,6 +65,11 @@ bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 // output order.  Fast kernel: same traversal and candidate mechanics, result set kept as a sorted
 // register array; queries whose answer could depend on the result heap's layout are flagged ST_HAZARD.
 hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+// Group kernel (group_search.hip): four queries per wavefront, persistent grid; same contract as the fast kernel.
+bool group_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
+bool group_q_in_regs(int metric, uint32_t dim);
+size_t group_lds_bytes(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots, bool q_in_regs);
+hipError_t launch_group(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 
 }  // namespace hs
