@@ -25,6 +25,8 @@ EXPORTS = [
     "hs_build_hnsw", "hs_build_hnsw_labeled", "hs_convert_slim", "hs_rabitq_rotate", "hs_rabitq_quantize_data", "hs_rabitq_prepare_query",
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
+    "hs_search_batch_async", "hs_host_alloc", "hs_host_free", "hs_comm_init", "hs_comm_free", "hs_comm_size", "hs_search_batch_sharded",
+    "hs_comm_results_dev",
 ]
 
 
@@ -73,6 +75,17 @@ def lib():
     L.hs_search_batch.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp]
     L.hs_search_batch_dev.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_search_check.argtypes = [vp, vp]
+    L.hs_search_batch_async.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
+    L.hs_host_alloc.restype = vp
+    L.hs_host_alloc.argtypes = [sz]
+    L.hs_host_free.restype = None
+    L.hs_host_free.argtypes = [vp]
+    L.hs_comm_init.argtypes = [ci, vp, ctypes.POINTER(vp)]
+    L.hs_comm_free.restype = None
+    L.hs_comm_free.argtypes = [vp]
+    L.hs_comm_size.argtypes = [vp]
+    L.hs_search_batch_sharded.argtypes = [vp, vp, vp, sz, sz, ci, vp, vp, vp, vp]
+    L.hs_comm_results_dev.argtypes = [vp, ci, vp, vp, vp, vp]
     L.hs_search_batch_raw.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp]
     L.hs_search_batch_filtered.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.hs_labels.argtypes = [vp, vp]
@@ -189,6 +202,69 @@ def rabitq_estimate(codes, fac, q3, bins, g_add, g_error):
     _check(lib().hs_rabitq_estimate(nblk * 64, a[0].ctypes.data, a[1].ctypes.data, nd, a[2].ctypes.data, a[3].ctypes.data,
                                     a[4].ctypes.data, a[5].ctypes.data, nq, out.ctypes.data))
     return out
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory (hs_host_alloc), for the asynchronous host-pointer entry."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().hs_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise HsError(HS_ERR_NOMEM, "hs_host_alloc failed")
+        buf = (ctypes.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+        self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            self.a = None
+            lib().hs_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+class Comm:
+    """hs_comm: n devices of one process (the same device listed twice = the one-GPU rehearsal mode)."""
+
+    def __init__(self, devices):
+        self._h = ctypes.c_void_p()
+        dv = (ctypes.c_int * len(devices))(*devices)
+        _check(lib().hs_comm_init(len(devices), dv, ctypes.byref(self._h)))
+        self.devices = list(devices)
+
+    def close(self):
+        if self._h:
+            lib().hs_comm_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_ids(self, replicas, queries, k, want_dists=False):
+        """HS_MODE_SLIM_IDS over the replicas (Index objects, one per device of the communicator)."""
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        hs_ = (ctypes.c_void_p * len(replicas))(*[r._h for r in replicas])
+        labels = np.empty((nq, k), np.uint32)
+        dists = np.empty((nq, k), np.float32) if want_dists else None
+        cnt = np.empty(nq, np.uint32)
+        _check(lib().hs_search_batch_sharded(self._h, hs_, q.ctypes.data, nq, k, HS_MODE_SLIM_IDS, labels.ctypes.data, None,
+                                             dists.ctypes.data if want_dists else None, cnt.ctypes.data))
+        return dict(labels=labels, dists=dists, cnt=cnt)
+
+    def search_pq(self, replicas, queries, k):
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        hs_ = (ctypes.c_void_p * len(replicas))(*[r._h for r in replicas])
+        labels = np.empty((nq, k), np.uint64)
+        dists = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        _check(lib().hs_search_batch_sharded(self._h, hs_, q.ctypes.data, nq, k, HS_MODE_PQ, None, labels.ctypes.data, dists.ctypes.data,
+                                             cnt.ctypes.data))
+        return dict(labels=labels, dists=dists, cnt=cnt)
 
 
 class Index:
@@ -310,6 +386,12 @@ class Index:
         _check(lib().hs_search_batch_raw(self._h, q.ctypes.data, nq, k, mode, rd.ctypes.data, ri.ctypes.data, rs.ctypes.data,
                                          stats.ctypes.data))
         return dict(raw_d=rd, raw_i=ri, raw_sz=rs, stats=stats)
+
+    def search_ids_async(self, q_pinned, k, labels_pinned, stream=0, dists_pinned=None, counts_pinned=None):
+        """hs_search_batch_async, HS_MODE_SLIM_IDS: numpy views of page-locked memory (PinnedArray.a), a HIP stream handle."""
+        _check(lib().hs_search_batch_async(self._h, q_pinned.ctypes.data, q_pinned.shape[0], k, HS_MODE_SLIM_IDS, labels_pinned.ctypes.data, None,
+                                           dists_pinned.ctypes.data if dists_pinned is not None else None,
+                                           counts_pinned.ctypes.data if counts_pinned is not None else None, None, stream))
 
     # -- device-pointer API (torch tensors on this index's device; async on `stream`) ----------------
     def search_ids_dev(self, d_queries, k, d_labels, d_dists=None, d_counts=None, d_stats=None, stream=0):

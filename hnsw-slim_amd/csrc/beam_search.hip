@@ -1066,8 +1066,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
   }
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
+#ifndef HS_FAST_WAVES
+#define HS_FAST_WAVES 4
+#endif
 template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) fast_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_FAST_WAVES))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
     if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;  // pass 0 takes every query

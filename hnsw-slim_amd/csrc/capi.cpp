@@ -3,6 +3,8 @@
 // exists in this library: without a HIP device every search call returns HS_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -86,6 +88,10 @@ struct hs_index {
     DevBuf<uint32_t> prep;              // SlimQ: per-query preparation records
     DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, tier-2 spills}
     size_t last_nq = 0;
+    // hs_search_batch_async: device staging of the queries and outputs of the call in flight on this stream
+    DevBuf<float> aq, adist;
+    DevBuf<uint32_t> al32, acnt, astats;
+    DevBuf<uint64_t> al64;
   };
   std::map<hipStream_t, std::unique_ptr<StreamWs>> ws;
   std::mutex ws_mu;
@@ -482,8 +488,10 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
                     fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, sh.hash_slots) <= kLdsPerCU;
-  static const bool no_group = getenv("HS_NO_GROUP") != nullptr;   // diagnostic knob: keep the one-query-per-wave fast kernel
-  const bool group = !no_group && !ix->exact_order && !raw && group_supported(ix->dev, sh.ef, (uint32_t)k) &&
+  // The four-queries-per-wavefront kernel (group_search.hip) is parity-green but measured slower than the one-query-per-wave
+  // fast kernel on MI355X: HS_GROUP=1 selects it for A/B runs and for its parity tests.
+  static const bool use_group = getenv("HS_GROUP") != nullptr;
+  const bool group = use_group && !ix->exact_order && !raw && group_supported(ix->dev, sh.ef, (uint32_t)k) &&
                      group_lds_bytes((uint32_t)ix->info.dim, sh.g_cand_cap, sh.g_hash_slots, group_q_in_regs(ix->info.metric, (uint32_t)ix->info.dim)) <= kLdsPerCU;
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
@@ -582,52 +590,94 @@ hs_status hs_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, s
                     nullptr, nullptr, (hipStream_t)stream);
 }
 
+// H2D of the queries, the search, D2H of the requested outputs: all enqueued on `stream`, no host synchronisation.  The
+// staging buffers belong to (index, stream): a second call on the same stream reuses them in stream order.
+static hs_status search_async(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *l32, uint64_t *l64,
+                              float *dd, uint32_t *cnt, uint32_t *stats, hipStream_t st) {
+  if (!ix || !queries) return fail(HS_ERR_INVALID, "null argument");
+  if (k == 0) return fail(HS_ERR_INVALID, "k must be > 0");
+  if (nq == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t dim = ix->info.dim;
+  hs_index::StreamWs *w = ix->stream_ws(st);
+  HIP_TRY(w->aq.ensure(nq * dim));
+  if (l32 || mode == HS_MODE_SLIM_IDS) HIP_TRY(w->al32.ensure(nq * k));
+  if (l64 || mode == HS_MODE_PQ) HIP_TRY(w->al64.ensure(nq * k));
+  if (dd || mode == HS_MODE_PQ) HIP_TRY(w->adist.ensure(nq * k));
+  HIP_TRY(w->acnt.ensure(nq));
+  if (stats) HIP_TRY(w->astats.ensure(nq * 4));
+  HIP_TRY(hipMemcpyAsync(w->aq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+  const bool ids = mode == HS_MODE_SLIM_IDS;
+  hs_status s = search_dev(ix, w->aq.p, nq, k, mode, (l32 || ids) ? w->al32.p : nullptr, (l64 || !ids) ? w->al64.p : nullptr,
+                           (dd || !ids) ? w->adist.p : nullptr, w->acnt.p, stats ? w->astats.p : nullptr, nullptr, nullptr, st);
+  if (s != HS_OK) return s;
+  if (l32) HIP_TRY(hipMemcpyAsync(l32, w->al32.p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  if (l64) HIP_TRY(hipMemcpyAsync(l64, w->al64.p, nq * k * 8, hipMemcpyDeviceToHost, st));
+  if (dd) HIP_TRY(hipMemcpyAsync(dd, w->adist.p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  if (cnt) HIP_TRY(hipMemcpyAsync(cnt, w->acnt.p, nq * 4, hipMemcpyDeviceToHost, st));
+  if (stats) HIP_TRY(hipMemcpyAsync(stats, w->astats.p, nq * 16, hipMemcpyDeviceToHost, st));
+  return HS_OK;
+}
+
 static hs_status search_host(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *l32,
                              uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, float *raw_d, uint32_t *raw_i,
                              uint32_t *raw_sz) {
   if (!ix || !queries) return fail(HS_ERR_INVALID, "null argument");
   if (nq == 0) return HS_OK;
+  const bool want_raw = raw_d || raw_i || raw_sz;
+  if (!want_raw) {   // one stream-ordered sequence of copies and launches, one synchronisation
+    hs_status s = search_async(ix, queries, nq, k, mode, l32, l64, dd, cnt, stats, nullptr);
+    if (s != HS_OK) return s;
+    return hs_search_check(ix, nullptr);
+  }
   HIP_TRY(hipSetDevice(ix->device));
   const size_t dim = ix->info.dim;
   const size_t ef = std::max(ix->ef, k);
   HIP_TRY(ix->wq.ensure(nq * dim));
+  HIP_TRY(ix->wstats.ensure(nq * 4));
+  HIP_TRY(ix->wraw.ensure(nq * ef));
+  HIP_TRY(ix->wrawsz.ensure(nq));
+  hipStream_t st = nullptr;
+  HIP_TRY(hipMemcpyAsync(ix->wq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
   HIP_TRY(ix->wl32.ensure(nq * k));
   HIP_TRY(ix->wl64.ensure(nq * k));
   HIP_TRY(ix->wdist.ensure(nq * k));
   HIP_TRY(ix->wcnt.ensure(nq));
-  HIP_TRY(ix->wstats.ensure(nq * 4));
-  const bool want_raw = raw_d || raw_i || raw_sz;
-  if (want_raw) {
-    HIP_TRY(ix->wraw.ensure(nq * ef));
-    HIP_TRY(ix->wrawsz.ensure(nq));
-  }
-  hipStream_t st = nullptr;
-  HIP_TRY(hipMemcpyAsync(ix->wq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
   hs_status s = search_dev(ix, ix->wq.p, nq, k, mode, ix->wl32.p, ix->wl64.p, ix->wdist.p, ix->wcnt.p, ix->wstats.p,
-                           want_raw ? ix->wraw.p : nullptr, want_raw ? ix->wrawsz.p : nullptr, st);
+                           ix->wraw.p, ix->wrawsz.p, st);
   if (s != HS_OK) return s;
   s = hs_search_check(ix, st);
   if (s != HS_OK) return s;
-  if (l32) HIP_TRY(hipMemcpy(l32, ix->wl32.p, nq * k * 4, hipMemcpyDeviceToHost));
-  if (l64) HIP_TRY(hipMemcpy(l64, ix->wl64.p, nq * k * 8, hipMemcpyDeviceToHost));
-  if (dd) HIP_TRY(hipMemcpy(dd, ix->wdist.p, nq * k * 4, hipMemcpyDeviceToHost));
-  if (cnt) HIP_TRY(hipMemcpy(cnt, ix->wcnt.p, nq * 4, hipMemcpyDeviceToHost));
   if (stats) HIP_TRY(hipMemcpy(stats, ix->wstats.p, nq * 16, hipMemcpyDeviceToHost));
-  if (want_raw) {
-    std::vector<Pair> raw(nq * ef);
-    std::vector<uint32_t> sz(nq);
-    HIP_TRY(hipMemcpy(raw.data(), ix->wraw.p, nq * ef * sizeof(Pair), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sz.data(), ix->wrawsz.p, nq * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < nq; i++) {
-      if (raw_sz) raw_sz[i] = sz[i];
-      for (size_t j = 0; j < ef; j++) {
-        const bool v = j < sz[i];
-        if (raw_d) raw_d[i * ef + j] = v ? raw[i * ef + j].d : 0.f;
-        if (raw_i) raw_i[i * ef + j] = v ? raw[i * ef + j].id : 0u;
-      }
+  std::vector<Pair> raw(nq * ef);
+  std::vector<uint32_t> sz(nq);
+  HIP_TRY(hipMemcpy(raw.data(), ix->wraw.p, nq * ef * sizeof(Pair), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sz.data(), ix->wrawsz.p, nq * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nq; i++) {
+    if (raw_sz) raw_sz[i] = sz[i];
+    for (size_t j = 0; j < ef; j++) {
+      const bool v = j < sz[i];
+      if (raw_d) raw_d[i * ef + j] = v ? raw[i * ef + j].d : 0.f;
+      if (raw_i) raw_i[i * ef + j] = v ? raw[i * ef + j].id : 0u;
     }
   }
   return HS_OK;
+}
+
+hs_status hs_search_batch_async(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *out_labels32,
+                                uint64_t *out_labels64, float *out_dists, uint32_t *out_counts, uint32_t *stats, void *stream) {
+  if (mode == HS_MODE_SLIM_IDS && !out_labels32) return fail(HS_ERR_INVALID, "out_labels32 required");
+  if (mode == HS_MODE_PQ && (!out_labels64 || !out_dists || !out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
+  if (mode != HS_MODE_SLIM_IDS && mode != HS_MODE_PQ) return fail(HS_ERR_INVALID, "bad mode");
+  return search_async(ix, queries, nq, k, mode, out_labels32, out_labels64, out_dists, out_counts, stats, (hipStream_t)stream);
+}
+void *hs_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void hs_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *out_labels32,
@@ -968,6 +1018,200 @@ hs_status hs_rabitq_estimate(size_t padded, const uint64_t *codes, const float *
       float *o = out + (i * nd + j) * 3;
       o[0] = ip; o[1] = est; o[2] = est - factors[j * 3 + 2] * g_error[i];
     }
+  return HS_OK;
+}
+
+
+// ---- multi-GPU: replicated index, contiguous query shards, one all-gather of the packed results --------
+// One process drives n devices; every call below is asynchronous on a per-device stream, so a single host thread
+// enqueues the whole step (RCCL's single-process group API: ncclCommInitAll + ncclGroupStart/End).  RCCL is opened with
+// dlopen (RTLD_LOCAL): no link-time dependency, and a host process that already carries another RCCL build (PyTorch
+// bundles one) keeps its own symbols.
+struct hs_comm {
+  int n = 0;
+  std::vector<int> dev;
+  bool loopback = false;   // the same device listed more than once (1-GPU rehearsal): the gather runs as device copies
+  void *lib = nullptr;
+  std::vector<void *> comms;
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> done;
+  struct Dev {
+    DevBuf<float> q, all_dist;
+    DevBuf<uint32_t> all_l32, all_cnt;
+    DevBuf<uint64_t> all_l64;
+  };
+  std::vector<std::unique_ptr<Dev>> d;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+enum { kNcclUint8 = 1, kNcclUint32 = 3, kNcclUint64 = 5, kNcclFloat32 = 7 };   // ncclDataType_t (rccl.h)
+
+void hs_comm_free(hs_comm *c) {
+  if (!c) return;
+  for (int r = 0; r < (int)c->dev.size(); r++) {
+    (void)hipSetDevice(c->dev[r]);
+    if (r < (int)c->comms.size() && c->comms[r] && c->CommDestroy) c->CommDestroy(c->comms[r]);
+    if (r < (int)c->d.size()) c->d[r].reset();
+    if (r < (int)c->done.size() && c->done[r]) (void)hipEventDestroy(c->done[r]);
+    if (r < (int)c->streams.size() && c->streams[r]) (void)hipStreamDestroy(c->streams[r]);
+  }
+  if (c->lib) dlclose(c->lib);
+  delete c;
+}
+
+hs_status hs_comm_init(int n_gpus, const int *devices, hs_comm **out) {
+  if (!out || n_gpus < 1 || n_gpus > 64) return fail(HS_ERR_INVALID, "bad argument");
+  const int have = hs_device_count();
+  if (have < 1) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
+  std::unique_ptr<hs_comm, void (*)(hs_comm *)> c(new hs_comm(), hs_comm_free);
+  c->n = n_gpus;
+  for (int r = 0; r < n_gpus; r++) {
+    const int d = devices ? devices[r] : r;
+    if (d < 0 || d >= have) return fail(HS_ERR_DEVICE, "device " + std::to_string(d) + " not present (" + std::to_string(have) + " visible)");
+    for (int t = 0; t < r; t++) c->loopback = c->loopback || c->dev[t] == d;
+    c->dev.push_back(d);
+  }
+  c->streams.assign(n_gpus, nullptr);
+  c->done.assign(n_gpus, nullptr);
+  for (int r = 0; r < n_gpus; r++) {
+    HIP_TRY(hipSetDevice(c->dev[r]));
+    HIP_TRY(hipStreamCreateWithFlags(&c->streams[r], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->done[r], hipEventDisableTiming));
+    c->d.emplace_back(new hs_comm::Dev());
+  }
+  if (n_gpus > 1 && !c->loopback) {
+    c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!c->lib) return fail(HS_ERR_UNSUPPORTED, std::string("RCCL not found: ") + dlerror());
+    c->CommInitAll = (int (*)(void **, int, const int *))dlsym(c->lib, "ncclCommInitAll");
+    c->CommDestroy = (int (*)(void *))dlsym(c->lib, "ncclCommDestroy");
+    c->AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(c->lib, "ncclAllGather");
+    c->GroupStart = (int (*)())dlsym(c->lib, "ncclGroupStart");
+    c->GroupEnd = (int (*)())dlsym(c->lib, "ncclGroupEnd");
+    c->GetErrorString = (const char *(*)(int))dlsym(c->lib, "ncclGetErrorString");
+    if (!c->CommInitAll || !c->CommDestroy || !c->AllGather || !c->GroupStart || !c->GroupEnd)
+      return fail(HS_ERR_UNSUPPORTED, "RCCL library lacks the expected entry points");
+    c->comms.assign(n_gpus, nullptr);
+    const int rc = c->CommInitAll(c->comms.data(), n_gpus, c->dev.data());
+    if (rc != 0) return fail(HS_ERR_DEVICE, std::string("ncclCommInitAll: ") + (c->GetErrorString ? c->GetErrorString(rc) : "error"));
+  }
+  *out = c.release();
+  return HS_OK;
+}
+
+int hs_comm_size(const hs_comm *c) { return c ? c->n : 0; }
+
+#define NCCL_TRY(c, expr)                                                                                  \
+  do {                                                                                                     \
+    const int _rc = (expr);                                                                                \
+    if (_rc != 0) return fail(HS_ERR_DEVICE, std::string(#expr ": ") + ((c)->GetErrorString ? (c)->GetErrorString(_rc) : "RCCL error")); \
+  } while (0)
+
+// Shard r = rows [r * S, min(nq, (r + 1) * S)), S = ceil(nq / n): device r searches its shard straight into slot r of
+// its [n * S x k] gather buffers, the in-place all-gather completes the other slots, device 0's copy goes to the host.
+hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
+                                  uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts) {
+  if (!c || !ixs || !queries) return fail(HS_ERR_INVALID, "null argument");
+  if (mode == HS_MODE_SLIM_IDS && !out_labels32) return fail(HS_ERR_INVALID, "out_labels32 required");
+  if (mode == HS_MODE_PQ && (!out_labels64 || !out_dists || !out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
+  if (mode != HS_MODE_SLIM_IDS && mode != HS_MODE_PQ) return fail(HS_ERR_INVALID, "bad mode");
+  if (k == 0) return fail(HS_ERR_INVALID, "k must be > 0");
+  const int n = c->n;
+  for (int r = 0; r < n; r++) {
+    if (!ixs[r]) return fail(HS_ERR_INVALID, "null index replica");
+    if (ixs[r]->device != c->dev[r]) return fail(HS_ERR_INVALID, "replica " + std::to_string(r) + " is not on the communicator's device");
+    if (ixs[r]->info.n != ixs[0]->info.n || ixs[r]->info.dim != ixs[0]->info.dim || ixs[r]->info.kind != ixs[0]->info.kind)
+      return fail(HS_ERR_INVALID, "replicas differ");
+  }
+  if (nq == 0) return HS_OK;
+  const size_t dim = ixs[0]->info.dim, S = (nq + n - 1) / n;
+  const bool ids = mode == HS_MODE_SLIM_IDS;
+  const bool want_d = out_dists != nullptr, want_c = out_counts != nullptr || !ids;
+  for (int r = 0; r < n; r++) {
+    HIP_TRY(hipSetDevice(c->dev[r]));
+    hs_comm::Dev &d = *c->d[r];
+    HIP_TRY(d.q.ensure(S * dim));
+    if (ids) HIP_TRY(d.all_l32.ensure((size_t)n * S * k));
+    else HIP_TRY(d.all_l64.ensure((size_t)n * S * k));
+    if (want_d || !ids) HIP_TRY(d.all_dist.ensure((size_t)n * S * k));
+    HIP_TRY(d.all_cnt.ensure((size_t)n * S));
+    const size_t lo = std::min(nq, (size_t)r * S), m = std::min(nq, lo + S) - lo;
+    hipStream_t st = c->streams[r];
+    if (m < S) {   // a short (or empty) last shard: its padding rows must not be garbage in the gathered arrays
+      if (ids) HIP_TRY(hipMemsetAsync(d.all_l32.p + (size_t)r * S * k, 0xFF, S * k * 4, st));
+      else HIP_TRY(hipMemsetAsync(d.all_l64.p + (size_t)r * S * k, 0xFF, S * k * 8, st));
+      HIP_TRY(hipMemsetAsync(d.all_cnt.p + (size_t)r * S, 0, S * 4, st));
+    }
+    if (m) {
+      HIP_TRY(hipMemcpyAsync(d.q.p, queries + lo * dim, m * dim * sizeof(float), hipMemcpyHostToDevice, st));
+      hs_status s = search_dev(ixs[r], d.q.p, m, k, mode, ids ? d.all_l32.p + (size_t)r * S * k : nullptr,
+                               ids ? nullptr : d.all_l64.p + (size_t)r * S * k, (want_d || !ids) ? d.all_dist.p + (size_t)r * S * k : nullptr,
+                               d.all_cnt.p + (size_t)r * S, nullptr, nullptr, nullptr, st);
+      if (s != HS_OK) return s;
+    }
+    if (c->loopback) HIP_TRY(hipEventRecord(c->done[r], st));
+  }
+  if (n > 1 && !c->loopback) {
+    NCCL_TRY(c, c->GroupStart());
+    for (int r = 0; r < n; r++) {
+      hs_comm::Dev &d = *c->d[r];
+      hipStream_t st = c->streams[r];
+      if (ids) NCCL_TRY(c, c->AllGather(d.all_l32.p + (size_t)r * S * k, d.all_l32.p, S * k, kNcclUint32, c->comms[r], st));
+      else NCCL_TRY(c, c->AllGather(d.all_l64.p + (size_t)r * S * k, d.all_l64.p, S * k, kNcclUint64, c->comms[r], st));
+      if (want_d || !ids) NCCL_TRY(c, c->AllGather(d.all_dist.p + (size_t)r * S * k, d.all_dist.p, S * k, kNcclFloat32, c->comms[r], st));
+      if (want_c) NCCL_TRY(c, c->AllGather(d.all_cnt.p + (size_t)r * S, d.all_cnt.p, S, kNcclUint32, c->comms[r], st));
+    }
+    NCCL_TRY(c, c->GroupEnd());
+  } else if (n > 1) {
+    // rehearsal on one device: the same exchange as stream-ordered device copies (slot s of every rank <- slot s of rank s)
+    for (int r = 0; r < n; r++) {
+      HIP_TRY(hipSetDevice(c->dev[r]));
+      hs_comm::Dev &d = *c->d[r];
+      hipStream_t st = c->streams[r];
+      for (int s2 = 0; s2 < n; s2++) {
+        if (s2 == r) continue;
+        hs_comm::Dev &o = *c->d[s2];
+        HIP_TRY(hipStreamWaitEvent(st, c->done[s2], 0));
+        if (ids) HIP_TRY(hipMemcpyAsync(d.all_l32.p + (size_t)s2 * S * k, o.all_l32.p + (size_t)s2 * S * k, S * k * 4, hipMemcpyDeviceToDevice, st));
+        else HIP_TRY(hipMemcpyAsync(d.all_l64.p + (size_t)s2 * S * k, o.all_l64.p + (size_t)s2 * S * k, S * k * 8, hipMemcpyDeviceToDevice, st));
+        if (want_d || !ids) HIP_TRY(hipMemcpyAsync(d.all_dist.p + (size_t)s2 * S * k, o.all_dist.p + (size_t)s2 * S * k, S * k * 4, hipMemcpyDeviceToDevice, st));
+        if (want_c) HIP_TRY(hipMemcpyAsync(d.all_cnt.p + (size_t)s2 * S, o.all_cnt.p + (size_t)s2 * S, S * 4, hipMemcpyDeviceToDevice, st));
+      }
+    }
+  }
+  // the host takes the first nq rows of device 0's gathered arrays
+  {
+    HIP_TRY(hipSetDevice(c->dev[0]));
+    hs_comm::Dev &d = *c->d[0];
+    hipStream_t st = c->streams[0];
+    if (out_labels32) HIP_TRY(hipMemcpyAsync(out_labels32, d.all_l32.p, nq * k * 4, hipMemcpyDeviceToHost, st));
+    if (out_labels64) HIP_TRY(hipMemcpyAsync(out_labels64, d.all_l64.p, nq * k * 8, hipMemcpyDeviceToHost, st));
+    if (out_dists) HIP_TRY(hipMemcpyAsync(out_dists, d.all_dist.p, nq * k * 4, hipMemcpyDeviceToHost, st));
+    if (out_counts) HIP_TRY(hipMemcpyAsync(out_counts, d.all_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
+  }
+  hs_status worst = HS_OK;
+  std::string msg;
+  for (int r = 0; r < n; r++) {   // synchronises every device's stream and reports capacity errors
+    hs_status s = hs_search_check(ixs[r], c->streams[r]);
+    if (s != HS_OK && worst == HS_OK) { worst = s; msg = g_err; }
+  }
+  if (worst != HS_OK) return fail(worst, msg);
+  return HS_OK;
+}
+// The gathered result arrays as device `rank` holds them after hs_search_batch_sharded ([n * ceil(nq / n) x k], valid until
+// the next call): every device has the whole batch's top-k, e.g. for a re-ranking stage that runs on all of them.
+hs_status hs_comm_results_dev(hs_comm *c, int rank, const uint32_t **d_labels32, const uint64_t **d_labels64, const float **d_dists,
+                              const uint32_t **d_counts) {
+  if (!c || rank < 0 || rank >= c->n) return fail(HS_ERR_INVALID, "bad argument");
+  hs_comm::Dev &d = *c->d[rank];
+  if (d_labels32) *d_labels32 = d.all_l32.p;
+  if (d_labels64) *d_labels64 = d.all_l64.p;
+  if (d_dists) *d_dists = d.all_dist.p;
+  if (d_counts) *d_counts = d.all_cnt.p;
   return HS_OK;
 }
 

@@ -116,15 +116,36 @@ class DeviceIndex {
   int metric_ = HS_METRIC_L2;
   size_t dim_ = 0;
   int device_ = 0;
+  // more than one device: the index is replicated and searchKnnBatch shards the batch (hs_search_batch_sharded);
+  // replicas_[0] == h_.  Single-query searchKnn stays on the first device.
+  std::vector<int> devices_;
+  std::vector<hs_index *> replicas_;
+  hs_comm *comm_ = nullptr;
+  void free_replicas() {
+    for (size_t r = 1; r < replicas_.size(); r++) hs_index_free(replicas_[r]);
+    replicas_.clear();
+    hs_comm_free(comm_);
+    comm_ = nullptr;
+  }
 
  public:
   size_t ef_ = 10;
-  ~DeviceIndex() { hs_index_free(h_); }
-  void setDevice(int device) { device_ = device; }
+  ~DeviceIndex() {
+    free_replicas();
+    hs_index_free(h_);
+  }
+  void setDevice(int device) { device_ = device; devices_.clear(); }
+  // Call before loadIndex: replicate the index on these devices (e.g. {0,1,...,7} on one MI355X node).
+  void setDevices(const std::vector<int> &devices) {
+    devices_ = devices;
+    if (!devices.empty()) device_ = devices[0];
+  }
   void setEf(size_t ef) {
     ef_ = ef;
     if (h_) check(hs_set_ef(h_, ef));
+    for (size_t r = 1; r < replicas_.size(); r++) check(hs_set_ef(replicas_[r], ef));
   }
+  bool sharded() const { return comm_ != nullptr; }
   hs_index *handle() const { return h_; }
   const std::string &path() const { return path_; }
   // indexSize(): the bytes the reference reports for this index's graph structure in ITS layout (hnswalg.h:1533-1547,
@@ -150,7 +171,17 @@ class DeviceIndex {
     metric_ = metric_of(s);
     dim_ = dim_of(s);
     path_ = location;
+    free_replicas();
     check(hs_index_load(location.c_str(), kind, metric_, dim_, max_elements, device_, &h_));
+    if (devices_.size() > 1) {
+      replicas_.assign(1, h_);
+      for (size_t r = 1; r < devices_.size(); r++) {
+        hs_index *h = nullptr;
+        check(hs_index_load(location.c_str(), kind, metric_, dim_, max_elements, devices_[r], &h));
+        replicas_.push_back(h);
+      }
+      check(hs_comm_init((int)devices_.size(), devices_.data(), &comm_));
+    }
     ef_ = 10;  // hnswalg.h:864, hnswalg_slim.h:793
   }
   mutable BaseFilterFunctor *cached_filter_ = nullptr;
@@ -263,7 +294,8 @@ class HierarchicalNSW<float> : public AlgorithmInterface<float>, public detail::
   void searchKnnBatch(const float *queries, size_t nq, size_t k, uint64_t *out_labels, float *out_dists,
                       uint32_t *out_counts) const {
     ensure_built();
-    detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_PQ, nullptr, out_labels, out_dists, out_counts, nullptr));
+    if (comm_) detail::check(hs_search_batch_sharded(comm_, replicas_.data(), queries, nq, k, HS_MODE_PQ, nullptr, out_labels, out_dists, out_counts));
+    else detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_PQ, nullptr, out_labels, out_dists, out_counts, nullptr));
   }
 };
 
@@ -345,10 +377,15 @@ class HierarchicalNSWSlim<float> : public AlgorithmInterface<float>, public deta
     detail::check(hs_search_batch(h_, (const float *)query_data, 1, k, HS_MODE_SLIM_IDS, result, nullptr, nullptr, nullptr, nullptr));
   }
   // The fast entry: every row of `queries` in one launch.
+  // With setDevices({...}) before loadIndex the batch is sharded over the devices and gathered (RCCL over xGMI).
   void searchKnnBatch(const float *queries, size_t nq, size_t k, tableint *results) const {
-    detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_SLIM_IDS, results, nullptr, nullptr, nullptr, nullptr));
+    if (comm_) detail::check(hs_search_batch_sharded(comm_, replicas_.data(), queries, nq, k, HS_MODE_SLIM_IDS, results, nullptr, nullptr, nullptr));
+    else detail::check(hs_search_batch(h_, queries, nq, k, HS_MODE_SLIM_IDS, results, nullptr, nullptr, nullptr, nullptr));
   }
-  void setExactOrder(bool on) { detail::check(hs_set_exact_order(h_, on ? 1 : 0)); }
+  void setExactOrder(bool on) {
+    detail::check(hs_set_exact_order(h_, on ? 1 : 0));
+    for (size_t r = 1; r < replicas_.size(); r++) detail::check(hs_set_exact_order(replicas_[r], on ? 1 : 0));
+  }
 };
 
 // BruteforceSearch (bruteforce.h): exhaustive scan.  addPoint keeps the rows on the host; searchKnn / searchKnnBatch

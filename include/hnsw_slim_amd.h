@@ -122,6 +122,38 @@ hs_status hs_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, s
                               uint32_t *d_out_counts, uint32_t *d_stats, void *stream);
 hs_status hs_search_check(hs_index *ix, void *stream);
 
+/* Host pointers, asynchronous: H2D of the queries, the search and D2H of the requested outputs are enqueued on `stream`
+ * and nothing is valid until that stream is synchronised (hs_search_check does it and reports capacity problems).  The
+ * serving shape of the reference's query loop (include/strategy/hnsw_slim_strategy.h:107-118: the clock runs around the
+ * whole loop, queries in, labels out): batches issued round-robin on a few streams overlap each other's copies and
+ * kernels.  queries and outputs should be page-locked (hs_host_alloc, or hipHostMalloc / hipHostRegister of the
+ * caller's own buffers): with pageable memory the copies are staged synchronously.  Staging buffers are per
+ * (index, stream): do not reuse a stream for a second call on the same index before the first one's outputs are read. */
+hs_status hs_search_batch_async(hs_index *ix, const float *queries, size_t nq, size_t k, int mode,
+                                uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists,
+                                uint32_t *out_counts, uint32_t *stats, void *stream);
+void *hs_host_alloc(size_t bytes);   /* page-locked host memory (NULL on failure) */
+void hs_host_free(void *p);
+
+/* ---- multi-GPU (no counterpart in the reference, which has no notion of a device) --------------------
+ * Queries are independent and the index is read-only during search: the index is REPLICATED (hs_index_load once per
+ * device), a batch is split into contiguous shards [r*S, (r+1)*S), S = ceil(nq/n), device r searches shard r, and one
+ * RCCL all-gather of the packed [S x k] results over xGMI leaves the whole [nq x k] result on every device and on the
+ * host.  One process, one stream per device; parity = the single-device result, bit for bit.
+ * hs_comm_init: devices = n_gpus HIP device ordinals (NULL: 0..n-1).  Listing one device more than once is the
+ * one-GPU rehearsal mode (the exchange then runs as device copies instead of RCCL, which refuses duplicate devices). */
+typedef struct hs_comm hs_comm;
+hs_status hs_comm_init(int n_gpus, const int *devices, hs_comm **out);
+void hs_comm_free(hs_comm *c);
+int hs_comm_size(const hs_comm *c);
+/* ixs: n_gpus replicas, ixs[r] loaded on the communicator's r-th device; queries and outputs are host pointers (outputs
+ * as for hs_search_batch; out_dists / out_counts nullable in HS_MODE_SLIM_IDS).  Synchronous. */
+hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
+                                  uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts);
+/* device `rank`'s copy of the gathered arrays of the last hs_search_batch_sharded call ([n_gpus * S x k]; valid until the next call) */
+hs_status hs_comm_results_dev(hs_comm *c, int rank, const uint32_t **d_labels32, const uint64_t **d_labels64,
+                              const float **d_dists, const uint32_t **d_counts);
+
 /* Parity/debug entry: raw top_candidates arrays after the level-0 beam, exactly as the reference holds
  * them before selection (hnswalg_slim.h:2116-2124): raw_dists/raw_ids are nq x max(ef,k), raw_sizes nq.
  * mark_ep_visited selects the (q,k)/(q,k,filter) overloads' extra visited tag (hnswalg_slim.h:1796,1919). */

@@ -96,6 +96,20 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (mode == "slim2") {
+    // two replicas (here: device 0 listed twice, the one-GPU rehearsal of a multi-device node): searchKnnBatch shards the
+    // batch over them and gathers; the strict order of the single-device call must come back
+    hnswlib::HierarchicalNSWSlim<float> ix(&space);
+    ix.setDevices({0, 0});
+    ix.loadIndex(path, &space);
+    ix.setEf(ef);
+    ix.setExactOrder(true);
+    if (!ix.sharded()) return 3;
+    std::vector<hnswlib::tableint> all(nq * k);
+    ix.searchKnnBatch(Q.data(), nq, k, all.data());
+    out.write((char *)all.data(), 4 * nq * k);
+    return 0;
+  }
   if (mode == "slim") {
     hnswlib::HierarchicalNSWSlim<float> ix(&space, path);
     ix.setEf(ef);
