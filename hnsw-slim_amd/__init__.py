@@ -26,7 +26,7 @@ EXPORTS = [
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
     "hs_search_batch_async", "hs_host_alloc", "hs_host_free", "hs_comm_init", "hs_comm_free", "hs_comm_size", "hs_search_batch_sharded",
-    "hs_comm_results_dev",
+    "hs_comm_results_dev", "hs_convert_slim_gpu",
 ]
 
 
@@ -91,6 +91,8 @@ def lib():
     L.hs_labels.argtypes = [vp, vp]
     L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
+    L.hs_convert_slim_gpu.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ci, ctypes.c_char_p,
+                                      ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
     L.hs_convert_slimq.argtypes = [ctypes.c_char_p, ci, sz, vp, sz, vp, ctypes.c_uint64, ci, ctypes.c_char_p]
     L.hs_rabitq_default_tconst.restype = ctypes.c_double
     L.hs_rabitq_default_tconst.argtypes = [sz, ctypes.c_uint64]
@@ -133,6 +135,16 @@ def convert_slim(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=
     """HierarchicalNSWSlim::convertFromHNSW + saveIndex, on the CPU (harness)."""
     _check(lib().hs_convert_slim(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
                                  top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
+
+
+def convert_slim_gpu(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=0, top_degree_percent0=0.02,
+                     top_degree_percent=0.02, top_degree_M0=32, low_degree_m0=8, top_degree_M=16, low_degree_m=4, device=0, threads=8):
+    """convertFromHNSW with the per-list work on the GPU; returns (used_gpu, kernel_ms).  Same bytes as convert_slim."""
+    used, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+    _check(lib().hs_convert_slim_gpu(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
+                                     top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, device, threads, out_path.encode(),
+                                     ctypes.byref(used), ctypes.byref(ms)))
+    return bool(used.value), ms.value
 
 
 def brute_force(base, queries, k, metric=HS_METRIC_L2, labels=None, device=0):

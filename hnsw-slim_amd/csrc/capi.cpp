@@ -19,6 +19,8 @@
 
 #include "../../include/hnsw_slim_amd.h"
 #include "engine.hpp"
+#define HS_HAVE_GPU_CONVERT 1
+#include "convert_engine.hpp"
 #include "host_graph.hpp"
 #include "rabitq_est.hpp"
 #include "rabitq_host.hpp"
@@ -899,6 +901,39 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
     p.top_M0 = top_degree_M0; p.low_m0 = low_degree_m0; p.top_M = top_degree_M; p.low_m = low_degree_m;
     SlimGraph s;
     s.convert(g, p, threads);
+    s.save(out_path);
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  return HS_OK;
+}
+
+// convertFromHNSW with the list-level work on the GPU (convert_gpu.hip); identical output bytes.  Shapes outside the device path
+// (degree capacities above 32, a reverse-edge list that outgrows the on-chip buffers) run the CPU conversion instead.
+hs_status hs_convert_slim_gpu(const char *hnsw_path, int metric, size_t dim, int threshold_level, float top_degree_percent0,
+                              float top_degree_percent, size_t top_degree_M0, size_t low_degree_m0, size_t top_degree_M,
+                              size_t low_degree_m, int device, int threads, const char *out_path, int *used_gpu, double *kernel_ms) {
+  if (!hnsw_path || !out_path) return fail(HS_ERR_INVALID, "bad argument");
+  if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device");
+  try {
+    VanillaGraph g;
+    g.load(hnsw_path, (Metric)metric, dim);
+    SlimParams p;
+    p.threshold_level = threshold_level;
+    p.top_pct0 = top_degree_percent0; p.top_pct = top_degree_percent;
+    p.top_M0 = top_degree_M0; p.low_m0 = low_degree_m0; p.top_M = top_degree_M; p.low_m = low_degree_m;
+    SlimGraph s;
+    std::string err;
+    double ms = 0.0;
+    const bool ok = s.convert_gpu(g, p, device, threads, &ms, &err);
+    if (!ok) {
+      if (!err.empty()) return fail(HS_ERR_DEVICE, err);
+      s.convert(g, p, threads);
+    }
+    if (used_gpu) *used_gpu = ok ? 1 : 0;
+    if (kernel_ms) *kernel_ms = ok ? ms : 0.0;
     s.save(out_path);
   } catch (std::bad_alloc &) {
     return fail(HS_ERR_NOMEM, "Not enough memory");

@@ -156,4 +156,86 @@ HS_HD void nth_element(P *a, long nth, long n, C comp) {
   }
 }
 
+// std::sort(a, a+n, comp) (bits/stl_algo.h: __introsort_loop + __final_insertion_sort), step for step, so that WHICH of
+// several equal-key entries ends up where is libstdc++'s choice -- convertFromHNSW sorts (distance, id) pairs by distance
+// only (hnswalg_slim.h:963-966, 1049-1052) before PruneByHeuristic, and the kept set depends on that order.
+// The recursion of __introsort_loop (right part recursed, left part looped) works on disjoint ranges, so an explicit stack
+// visiting them in any order leaves the same array.  Returns false if the stack would overflow (never for n < 2^31).
+template <class P, class C>
+HS_HD void insertion_sort_range(P *a, long first, long last, C comp, bool guarded) {
+  // std::__insertion_sort (guarded) / std::__unguarded_insertion_sort
+  if (first == last) return;
+  for (long i = guarded ? first + 1 : first; i != last; i++) {
+    Pair v = a[i];
+    if (guarded && comp(v, a[first])) {
+      for (long j = i; j > first; j--) a[j] = a[j - 1];
+      a[first] = v;
+    } else {  // std::__unguarded_linear_insert
+      long pos = i, next = i - 1;
+      while (comp(v, a[next])) {
+        a[pos] = a[next];
+        pos = next;
+        next--;
+      }
+      a[pos] = v;
+    }
+  }
+}
+template <class P, class C>
+HS_HD bool std_sort(P *a, long n, C comp) {
+  if (n < 2) return true;
+  long depth0 = 0;
+  for (long t = n; t > 1; t >>= 1) depth0++;
+  depth0 *= 2;
+  long stk_first[64], stk_last[64], stk_depth[64];
+  int sp = 0;
+  stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = depth0; sp = 1;
+  while (sp > 0) {
+    sp--;
+    long first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > 16) {
+      if (depth == 0) {
+        // std::__partial_sort(first, last, last): __heap_select (= make_heap, nothing beyond middle) + __sort_heap
+        make_heap(a + first, last - first, comp);
+        for (long m = last - first; m > 1; m--) pop_heap(a + first, m, comp);
+        break;
+      }
+      depth--;
+      // std::__unguarded_partition_pivot
+      const long mid = first + (last - first) / 2;
+      {
+        const long ia = first + 1, ib = mid, ic = last - 1;
+        if (comp(a[ia], a[ib])) {
+          if (comp(a[ib], a[ic])) swap_el(a, first, ib);
+          else if (comp(a[ia], a[ic])) swap_el(a, first, ic);
+          else swap_el(a, first, ia);
+        } else if (comp(a[ia], a[ic])) swap_el(a, first, ia);
+        else if (comp(a[ib], a[ic])) swap_el(a, first, ic);
+        else swap_el(a, first, ib);
+      }
+      long lo = first + 1, hi = last;
+      while (true) {
+        while (comp(a[lo], a[first])) lo++;
+        hi--;
+        while (comp(a[first], a[hi])) hi--;
+        if (!(lo < hi)) break;
+        swap_el(a, lo, hi);
+        lo++;
+      }
+      // __introsort_loop(cut, last, depth) ; last = cut
+      if (sp >= 64) return false;
+      stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth; sp++;
+      last = lo;
+    }
+  }
+  // std::__final_insertion_sort
+  if (n > 16) {
+    insertion_sort_range(a, 0, 16, comp, true);
+    insertion_sort_range(a, 16, n, comp, false);
+  } else {
+    insertion_sort_range(a, 0, n, comp, true);
+  }
+  return true;
+}
+
 }  // namespace hs

@@ -451,15 +451,10 @@ struct SlimGraph {
     }
   }
 
-  // convertFromHNSW (hnswalg_slim.h:867-1108).
-  void convert(const VanillaGraph &g, const SlimParams &p, int threads) {
-    count = g.count; dim = g.dim; metric = g.metric;
-    has_deleted = g.num_deleted() > 0;
-    maxM = g.maxM; maxM0 = g.maxM0; M = g.M; efC = g.efC;
-    maxlevel = g.maxlevel; enterpoint = g.enterpoint; threshold_level = p.threshold_level;
-    size_per_el = 24 + 4 * dim;
-    const size_t n = count;
-    // degree histograms per level (:904-922) and hub thresholds (:923-945)
+  // degree histograms per level (:904-922) and hub thresholds (:923-945)
+  static std::vector<size_t> hub_thresholds(const VanillaGraph &g, const SlimParams &p) {
+    const int maxlevel = g.maxlevel;
+    const size_t n = g.count, maxM0 = g.maxM0;
     std::vector<std::vector<size_t>> hist(maxlevel + 1, std::vector<size_t>(maxM0 + 2, 0));
     std::vector<size_t> level_cnts(maxlevel + 1, 0);
     for (size_t i = 0; i < n; i++) {
@@ -467,17 +462,59 @@ struct SlimGraph {
       hist[0][VanillaGraph::cnt_of(g.list_at(i, 0))]++;
     }
     std::vector<size_t> thr(maxlevel + 1, 0);
-    {
-      // NB: level_cnts[0] is never incremented by the reference (:910-912 start at l=1), so topN==0
-      // at level 0, `acc >= topN` holds at the first bucket and thr[0] = maxM0+1: no level-0 list is
-      // ever classed as a hub (every node is pruned to M_l0).  Mirrored, not fixed.
-      size_t acc = 0, topN = (size_t)(level_cnts[0] * p.top_pct0 + 0.5);
-      for (size_t d = hist[0].size() - 1; d > 0; --d) { acc += hist[0][d]; if (acc >= topN) { thr[0] = d; break; } }
-      for (int l = 1; l <= maxlevel; l++) {
-        acc = 0; topN = (size_t)(level_cnts[l] * p.top_pct + 0.5);
-        for (size_t d = hist[l].size() - 1; d > 0; --d) { acc += hist[l][d]; if (acc >= topN) { thr[l] = d; break; } }
-      }
+    // NB: level_cnts[0] is never incremented by the reference (:910-912 start at l=1), so topN==0
+    // at level 0, `acc >= topN` holds at the first bucket and thr[0] = maxM0+1: no level-0 list is
+    // ever classed as a hub (every node is pruned to M_l0).  Mirrored, not fixed.
+    size_t acc = 0, topN = (size_t)(level_cnts[0] * p.top_pct0 + 0.5);
+    for (size_t d = hist[0].size() - 1; d > 0; --d) { acc += hist[0][d]; if (acc >= topN) { thr[0] = d; break; } }
+    for (int l = 1; l <= maxlevel; l++) {
+      acc = 0; topN = (size_t)(level_cnts[l] * p.top_pct + 0.5);
+      for (size_t d = hist[l].size() - 1; d > 0; --d) { acc += hist[l][d]; if (acc >= topN) { thr[l] = d; break; } }
     }
+    return thr;
+  }
+  void take_header(const VanillaGraph &g, const SlimParams &p) {
+    count = g.count; dim = g.dim; metric = g.metric;
+    has_deleted = g.num_deleted() > 0;
+    maxM = g.maxM; maxM0 = g.maxM0; M = g.M; efC = g.efC;
+    maxlevel = g.maxlevel; enterpoint = g.enterpoint; threshold_level = p.threshold_level;
+    size_per_el = 24 + 4 * dim;
+  }
+  // Element i from its final per-level lists (after the re-prune): hierarchical filter (:1063-1084), offsets, blob (:1085-1106).
+  template <class GetList>
+  void assemble_node(const VanillaGraph &g, size_t i, GetList list_of) {
+    char *e = elements.data() + i * size_per_el;
+    int32_t L = g.levels[i];
+    memcpy(e, &L, 4);
+    memcpy(e + 24, g.vec(i), 4 * dim);
+    uint64_t lab = g.label(i);
+    memcpy(e + 8, &lab, 8);
+    std::vector<uint32_t> nbrs_out;
+    std::vector<uint16_t> offs;
+    for (int l = 0; l <= L; l++) {
+      size_t cnt = 0;
+      const uint32_t *nbrs = list_of(i, l, cnt);
+      if (l == threshold_level) {
+        nbrs_out.insert(nbrs_out.end(), nbrs, nbrs + cnt);
+      } else {  // hierarchical pruning: keep neighbours whose own top level == l (:1072-1083)
+        for (size_t j = 0; j < cnt; j++)
+          if (g.levels[nbrs[j]] == l) nbrs_out.push_back(nbrs[j]);
+      }
+      offs.push_back((uint16_t)nbrs_out.size());
+    }
+    uint32_t total = nbrs_out.size();
+    memcpy(e + 4, &total, 4);
+    if (total == 0) return;  // neighbors pointer stays null (:1091-1094)
+    blobs[i].resize(2 * (size_t)L + 4 * (size_t)total);
+    memcpy(blobs[i].data(), offs.data(), 2 * (size_t)L);
+    memcpy(blobs[i].data() + 2 * (size_t)L, nbrs_out.data(), 4 * (size_t)total);
+  }
+
+  // convertFromHNSW (hnswalg_slim.h:867-1108).
+  void convert(const VanillaGraph &g, const SlimParams &p, int threads) {
+    take_header(g, p);
+    const size_t n = count;
+    const std::vector<size_t> thr = hub_thresholds(g, p);
     std::vector<std::vector<std::vector<uint32_t>>> nn(n), rev(n);
     auto par = [&](auto fn) {
       int T = std::max(1, threads);
@@ -515,16 +552,8 @@ struct SlimGraph {
     elements.assign(n * size_per_el, 0);
     blobs.assign(n, {});
     par([&](size_t i) {  // :1014-1107
-      char *e = elements.data() + i * size_per_el;
-      int32_t L = g.levels[i];
-      memcpy(e, &L, 4);
-      memcpy(e + 24, g.vec(i), 4 * dim);
-      uint64_t lab = g.label(i);
-      memcpy(e + 8, &lab, 8);
-      std::vector<uint32_t> nbrs_out;
-      std::vector<uint16_t> offs;
       std::vector<pairfi> heap;
-      for (int l = 0; l <= L; l++) {
+      for (int l = 0; l <= g.levels[i]; l++) {
         auto &nbrs = nn[i][l];
         size_t limit = l == 0 ? maxM0 : maxM;
         if (nbrs.size() > limit) {  // re-prune (:1038-1062)
@@ -533,22 +562,71 @@ struct SlimGraph {
           std::sort(heap.begin(), heap.end(), CmpFirst());
           prune(g, heap, nbrs, limit);
         }
-        if (l == threshold_level) {
-          nbrs_out.insert(nbrs_out.end(), nbrs.begin(), nbrs.end());
-        } else {  // hierarchical pruning: keep neighbours whose own top level == l (:1072-1083)
-          for (uint32_t u : nbrs)
-            if (g.levels[u] == l) nbrs_out.push_back(u);
-        }
-        offs.push_back((uint16_t)nbrs_out.size());
       }
-      uint32_t total = nbrs_out.size();
-      memcpy(e + 4, &total, 4);
-      if (total == 0) return;  // neighbors pointer stays null (:1091-1094)
-      blobs[i].resize(2 * (size_t)L + 4 * (size_t)total);
-      memcpy(blobs[i].data(), offs.data(), 2 * (size_t)L);
-      memcpy(blobs[i].data() + 2 * (size_t)L, nbrs_out.data(), 4 * (size_t)total);
+      assemble_node(g, i, [&](size_t v, int l, size_t &cnt) { cnt = nn[v][l].size(); return nn[v][l].data(); });
     });
   }
+
+#ifdef HS_HAVE_GPU_CONVERT
+  // The same conversion with the list-level work on the GPU (convert_gpu.hip).  Returns false when the shape is outside the
+  // device path (lists longer than 64 / capacities above 32 ids, or a reverse-edge list that outgrew the on-chip buffers):
+  // the caller then runs convert().  kernel_ms: device time of the kernels.
+  bool convert_gpu(const VanillaGraph &g, const SlimParams &p, int device, int threads, double *kernel_ms, std::string *err) {
+    if (g.maxM0 > 32 || g.maxM > 32 || p.top_M0 > 32 || p.low_m0 > 32 || p.top_M > 32 || p.low_m > 32) return false;
+    take_header(g, p);
+    const size_t n = count;
+    const std::vector<size_t> thr = hub_thresholds(g, p);
+    ConvertInput in;
+    in.vec = nullptr; in.n = (uint32_t)n; in.dim = (uint32_t)dim; in.metric = (int)metric;
+    std::vector<float> rows(n * dim);
+    for (size_t i = 0; i < n; i++) memcpy(&rows[i * dim], g.vec(i), 4 * dim);
+    in.vec = rows.data();
+    in.upb.assign(n, 0);
+    size_t nup = 0;
+    for (size_t i = 0; i < n; i++) { in.upb[i] = (uint32_t)nup; nup += g.levels[i]; }
+    const size_t nt = n + nup;
+    in.t_node.resize(nt); in.t_level.resize(nt); in.t_off.resize(nt); in.t_size.resize(nt); in.t_mlim.resize(nt); in.t_limit.resize(nt);
+    auto add = [&](size_t t, size_t v, int l) {
+      const uint32_t *ll = g.list_at(v, l);
+      const size_t size = VanillaGraph::cnt_of(ll);
+      in.t_node[t] = (uint32_t)v; in.t_level[t] = (uint32_t)l; in.t_off[t] = (uint32_t)in.lists.size(); in.t_size[t] = (uint32_t)size;
+      in.t_mlim[t] = (uint32_t)(l == 0 ? (size > thr[l] ? p.top_M0 : p.low_m0) : (size > thr[l] ? p.top_M : p.low_m));   // :957-961, 969-973
+      in.t_limit[t] = (uint32_t)(l == 0 ? maxM0 : maxM);
+      in.lists.insert(in.lists.end(), ll + 1, ll + 1 + size);
+    };
+    in.lists.reserve(n * 16);
+    for (size_t v = 0; v < n; v++) add(v, v, 0);
+    for (size_t v = 0; v < n; v++)
+      for (int l = 1; l <= g.levels[v]; l++) add(n + in.upb[v] + l - 1, v, l);
+    for (size_t t = 0; t < nt; t++)
+      if (in.t_size[t] > 64) return false;
+    std::vector<uint32_t> fin, fin_cnt;
+    bool needs_host = false;
+    hipError_t e = gpu_convert_lists(in, device, fin, fin_cnt, needs_host, kernel_ms);
+    if (e != hipSuccess) {
+      if (err) *err = std::string("GPU convert: ") + hipGetErrorString(e);
+      return false;
+    }
+    if (needs_host) return false;
+    elements.assign(n * size_per_el, 0);
+    blobs.assign(n, {});
+    int T = std::max(1, threads);
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; t++)
+      pool.emplace_back([&]() {
+        for (size_t v0; (v0 = next.fetch_add(256)) < n;)
+          for (size_t i = v0; i < std::min(n, v0 + 256); i++)
+            assemble_node(g, i, [&](size_t v, int l, size_t &cnt) {
+              const size_t t2 = l == 0 ? v : n + in.upb[v] + l - 1;
+              cnt = fin_cnt[t2];
+              return fin.data() + t2 * 32;
+            });
+      });
+    for (auto &th : pool) th.join();
+    return true;
+  }
+#endif
 
   void save(const std::string &path) const {  // hnswalg_slim.h:717-751
     std::ofstream o(path, std::ios::binary);

@@ -79,6 +79,29 @@ static int run_nth(unsigned seed, int range) {
   return 0;
 }
 
+// hs::std_sort against std::sort with a by-key-only comparator on tie-heavy, sorted, reversed and organ-pipe inputs
+static int run_sort(unsigned seed, int range) {
+  std::mt19937 rng(seed);
+  for (int it = 0; it < 2000; it++) {
+    size_t n = 1 + rng() % (it % 5 == 0 ? 3000 : 200);
+    std::vector<P> s(n);
+    std::vector<hs::Pair> e(n);
+    for (size_t i = 0; i < n; i++) {
+      float d = (float)(rng() % range);
+      if (it % 7 == 0) d = (float)i;
+      if (it % 11 == 0) d = (float)(i < n / 2 ? i : n - i);
+      if (it % 13 == 0) d = (float)(n - i);
+      if (it % 17 == 0) d = (float)((i * 7919u) % 5);
+      s[i] = {d, (uint32_t)i};
+      e[i] = {d, (uint32_t)i};
+    }
+    std::sort(s.begin(), s.end(), LessP());
+    if (!hs::std_sort(e.data(), (long)n, hs::LessD())) return 5;
+    if (!same(s, e, n)) return 4;
+  }
+  return 0;
+}
+
 // selftest loadmem <vanilla index> <slim index> <dim>: the loaders read the serialized bytes from host memory
 // (BinSource / MemBuf, behind hs_index_load_mem) exactly as they read the files; a truncated buffer is rejected.
 static std::vector<char> slurp(const char *path) {
@@ -126,6 +149,7 @@ int main(int argc, char **argv) {
       if ((rc = run_heap(seed, range, LessP(), hs::LessD()))) break;
       if ((rc = run_heap(seed + 100, range, GreaterP(), hs::GreaterD()))) break;
       if ((rc = run_nth(seed + 200, range))) break;
+      if ((rc = run_sort(seed + 300, range))) break;
     }
   printf(rc ? "heap_emul MISMATCH rc=%d\n" : "heap_emul identical to libstdc++ (rc=%d)\n", rc);
   return rc;

@@ -215,6 +215,15 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
                           float top_degree_percent0, float top_degree_percent, size_t top_degree_M0,
                           size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int threads,
                           const char *out_path);
+/* The same conversion with the per-list work on HIP device `device` (per-node distances, the by-distance
+ * std::sort with libstdc++'s tie order, PruneByHeuristic :836-865, the reverse-edge union :988-1012, the re-prune
+ * :1038-1062); histograms, hub thresholds and the final assembly run on `threads` host threads.  The file is byte-identical
+ * to hs_convert_slim's.  Shapes outside the device path (degree capacities above 32, a reverse-edge list beyond 2048 ids)
+ * are converted on the CPU; *used_gpu (nullable) says which path ran, *kernel_ms (nullable) the device time. */
+hs_status hs_convert_slim_gpu(const char *hnsw_path, int metric, size_t dim, int threshold_level,
+                              float top_degree_percent0, float top_degree_percent, size_t top_degree_M0,
+                              size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int device, int threads,
+                              const char *out_path, int *used_gpu, double *kernel_ms);
 
 /* HierarchicalNSWSlimQ::convertFromHNSW's OUTPUT format + saveIndex (hnswalg_slimq.h:1471-1790, 1161-1216): keeps
  * the graph of an existing HierarchicalNSWSlim file and replaces the fp32 rows by RaBitQ records (cluster id,

@@ -120,3 +120,67 @@ def parse_slim(raw, dim):
     return dict(count=n, dim=dim, maxlevel=hdr[6], threshold_level=hdr[7], enterpoint=hdr[8], maxM=hdr[9], maxM0=hdr[10], M=hdr[11],
                 efC=hdr[12], has_deleted=hdr[13], level=level, lists=lists, labels=el[:, 8:16].copy().view(np.uint64)[:, 0],
                 rows=el[:, 24:].copy().view(np.float32))
+
+
+# ---- HierarchicalNSWSlimQ file (hnswalg_slimq.h:1161-1216 / 1218-1313) -------------------------------------------------
+SLIMQ_EXT = "<9QB"   # num_cluster, dim, padded_dim, offset_cluster_id, offset_bin_data, offset_ex_data, size_bin_data, size_ex_data, ex_bits, metric
+
+
+def parse_slimq(raw):
+    """Independent reader of a SlimQ file: Slim header + quantiser header + rotated centroids + rotator flips + elements
+    [i32 level][u32 total][u64 label][8 B ptr][u32 cluster][code padded/8 B][f_add f_rescale f_error][ex area] + blobs."""
+    h = struct.unpack_from(SLIM_HDR, raw, 0)
+    pos = struct.calcsize(SLIM_HDR)
+    x = struct.unpack_from(SLIMQ_EXT, raw, pos)
+    pos += struct.calcsize(SLIMQ_EXT)
+    n, spe = h[0], h[1]
+    ncl, dim, padded, off_cid, off_bin, off_ex, sbin, sex, ex_bits, metric = x
+    assert padded % 64 == 0 and sbin == padded // 8 + 12 and off_cid == 24 and off_bin == 28 and off_ex == 28 + sbin and spe == 28 + sbin + sex
+    cent = np.frombuffer(raw, np.float32, ncl * padded, pos).reshape(ncl, padded).copy()
+    pos += ncl * padded * 4
+    nflip = 4 * padded // 8
+    flips = np.frombuffer(raw, np.uint8, nflip, pos).copy()
+    pos += nflip
+    el = np.frombuffer(raw, np.uint8, n * spe, pos).reshape(n, spe)
+    pos += n * spe
+    level = el[:, 0:4].copy().view(np.int32)[:, 0]
+    total = el[:, 4:8].copy().view(np.uint32)[:, 0]
+    blobs = []
+    for i in range(n):
+        (sz,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        assert sz == 2 * int(level[i]) + 4 * int(total[i])
+        if sz and total[i]:
+            blobs.append(bytes(raw[pos:pos + sz]))
+            pos += sz
+        else:
+            blobs.append(b"")
+    assert pos == len(raw)
+    return dict(hdr=h, ext=x, centroids=cent, flips=flips, level=level, total=total, labels=el[:, 8:16].copy().view(np.uint64)[:, 0],
+                cluster=el[:, 24:28].copy().view(np.uint32)[:, 0], code=el[:, 28:28 + padded // 8].copy(),
+                factors=el[:, 28 + padded // 8:28 + padded // 8 + 12].copy().view(np.float32), blobs=blobs)
+
+
+def write_slimq(g, garbage_seed=777):
+    """Re-serialise a parsed SlimQ file from its fields; the bytes no function of the search path reads -- the 8 stale pointer bytes
+    of every element and the whole ex-data area (hnswalg_slimq.h:1498-1505; searchKnn(q,k,result) only touches the 1-bit
+    code and its three factors) -- are filled with garbage."""
+    h, x = g["hdr"], g["ext"]
+    n, spe = h[0], h[1]
+    padded, sbin = x[2], x[6]
+    rng = np.random.default_rng(garbage_seed)
+    el = rng.integers(1, 256, size=(n, spe), dtype=np.uint8)
+    el[:, 0:4] = g["level"].astype("<i4").view(np.uint8).reshape(n, 4)
+    el[:, 4:8] = g["total"].astype("<u4").view(np.uint8).reshape(n, 4)
+    el[:, 8:16] = g["labels"].astype("<u8").view(np.uint8).reshape(n, 8)
+    el[:, 24:28] = g["cluster"].astype("<u4").view(np.uint8).reshape(n, 4)
+    el[:, 28:28 + padded // 8] = g["code"]
+    el[:, 28 + padded // 8:28 + sbin] = np.ascontiguousarray(g["factors"], np.float32).view(np.uint8).reshape(n, 12)
+    out = [struct.pack(SLIM_HDR, *h), struct.pack(SLIMQ_EXT, *x), np.ascontiguousarray(g["centroids"], np.float32).tobytes(), g["flips"].tobytes(),
+           el.tobytes()]
+    for i in range(n):
+        b = g["blobs"][i]
+        out.append(struct.pack("<I", 2 * int(g["level"][i]) + 4 * int(g["total"][i])))
+        if b:
+            out.append(b)
+    return b"".join(out)

@@ -198,3 +198,27 @@ def test_slimq_cpp_facade(env):
     want = ox.search(q, 10)
     assert (want["counts"] == 10).all()
     assert np.array_equal(got[0], want["labels"].astype(np.uint32)) and np.array_equal(got[1], want["labels"].astype(np.uint32))
+
+
+def test_slimq_file_rewritten_by_python(env):
+    """A SlimQ file the repository's C++ did not write: the product's file parsed by the independent Python reader
+    (oracle/chal_encode.py, to the last byte) and re-serialised from its fields with garbage in every byte the search path
+    must not read (the 8 stale pointer bytes of each element, the whole ex-data area) -- product and oracle load it and
+    answer exactly as on the original."""
+    from hsutil import load_chal_encode
+    P, O, tmp = env
+    ce = load_chal_encode()
+    x = sift_like(3000 + 100, 128, seed=13, n_clusters=24)
+    base, q = x[:3000], x[3000:]
+    path = build(P, tmp, "rewrite", base, 0, 8)
+    raw = open(path, "rb").read()
+    g = ce.parse_slimq(raw)
+    assert g["ext"][1] == 128 and g["ext"][0] == 8 and len(g["blobs"]) == 3000
+    raw2 = ce.write_slimq(g)
+    assert len(raw2) == len(raw) and raw2 != raw
+    p2 = str(tmp / "rewrite.py.slimq")
+    open(p2, "wb").write(raw2)
+    a, _ = check(P, O, path, base, q, 0, 10, (40,))
+    b, _ = check(P, O, p2, base, q, 0, 10, (40,))
+    ra, rb = a.slimq_search(q, 10, want_stats=True), b.slimq_search(q, 10, want_stats=True)
+    assert np.array_equal(ra["labels"], rb["labels"]) and ra["dists"].tobytes() == rb["dists"].tobytes() and np.array_equal(ra["stats"], rb["stats"])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Parity-at-size + throughput on the other BASELINE.json shapes (not the bench line): GIST-like d=960 and
-DEEP-like d=96.  Usage: other_configs.py gist|deep [n]"""
+"""Parity-at-size + throughput on the other BASELINE.json shapes (not the bench line): GIST-like d=960 (configs[2]) and
+DEEP-like d=96 (configs[3]).  Usage: other_configs.py gist|deep [n]     env GEN="n_clusters,rank,sigma_sub,sigma_iso" overrides the
+generator (calibration runs), EFS the sweep.  Prints the sweep and, for the smallest ef with recall@10 >= 0.95, the operating point."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -12,26 +13,30 @@ hs = load_product()
 which = sys.argv[1]
 if which == "gist":
     n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 960, 1000
-    gen = lambda m, seed: np.clip(sift_like(m, d, seed, n_clusters=1024, rank=24, sigma_sub=40.0, sigma_iso=3.0, integer=False) / 255.0, 0, 1).astype(np.float32)
+    G = [float(x) for x in os.environ.get("GEN", "4096,16,40,1").split(",")]   # calibrated in round 2 (profiles/r02_cfg_gist1m_d960.log)
+    gen = lambda m, seed: np.clip(sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False) / 255.0, 0, 1).astype(np.float32)
 else:
     n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000, int(os.environ.get("DIM", "96")), 10000
+    G = [float(x) for x in os.environ.get("GEN", "32768,12,40,2").split(",")]
     def gen(m, seed):
-        x = sift_like(m, d, seed, n_clusters=8192, rank=12, sigma_sub=40.0, sigma_iso=4.0, integer=False, centre_lo=-60, centre_hi=60)
+        x = sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
 t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
 dev = torch.device("cuda", 0)
 with tempfile.TemporaryDirectory() as tmp:
     hp, sp = os.path.join(tmp, "h.bin"), os.path.join(tmp, "s.bin")
-    t0 = time.time(); hs.build_hnsw(base, hp, M=16, ef_construction=200, threads=64); tb = time.time() - t0
-    t0 = time.time(); hs.convert_slim(hp, sp, d, threads=64); tc = time.time() - t0
+    thr = min(len(os.sched_getaffinity(0)), 64)
+    t0 = time.time(); hs.build_hnsw(base, hp, M=16, ef_construction=200, threads=thr); tb = time.time() - t0
+    t0 = time.time(); hs.convert_slim(hp, sp, d, threads=thr); tc = time.time() - t0
     print(f"build {tb:.0f}s convert {tc:.0f}s", flush=True)
     ix = hs.Index(sp, hs.HS_KIND_SLIM, d)
     ox = Oracle().load(sp, "slim", 0, d)
 bt = torch.from_numpy(base).to(dev); qt = torch.from_numpy(q).to(dev)
-gt = ground_truth(torch, bt, qt, 10); del bt
+gt = ground_truth(torch, bt, qt, 10, hs); del bt
 lab = torch.empty((nq, 10), dtype=torch.int32, device=dev); cnt = torch.empty((nq,), dtype=torch.int32, device=dev); st = torch.empty((nq, 4), dtype=torch.int32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-for ef in (32, 64, 128, 256):
+op = None
+for ef in [int(e) for e in os.environ.get('EFS', '32,48,64,96,128,192,256').split(',')]:
     ix.set_ef(ef); ox.set_ef(ef)
     for _ in range(2):
         ix.search_ids_dev(qt, 10, lab, None, cnt, st, s); ix.check(s)
@@ -45,4 +50,10 @@ for ef in (32, 64, 128, 256):
     same = bool(np.array_equal(np.sort(L[:200], axis=1), np.sort(want["labels"], axis=1))) and bool(np.array_equal(S[:200, :3], want["counters"][:, :3]))
     by = (S[:, 0] * 4 * d + S[:, 2] * 4 + S[:, 1] * 8)
     print(f"ef={ef}: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} n_dist={S[:,0].mean():.0f} hops={S[:,1].mean():.0f} alg_GB/s={by.sum()/ms/1e6:.0f} "
-          f"passes(tie/overflow)={(S[:,3]==1).sum()}/{(S[:,3]==2).sum()} oracle_match_first200={same}", flush=True)
+          f"frac={by.sum()/ms/1e6/8000:.3f} passes(tie/overflow)={(S[:,3]==1).sum()}/{(S[:,3]==2).sum()} oracle_match_first200={same}", flush=True)
+    if op is None and recall_at_k(L, gt) >= 0.95:
+        op = (ef, recall_at_k(L, gt), nq / ms * 1e3, by.sum() / ms / 1e6)
+if op:
+    print(f"OPERATING POINT {which} n={n} d={d} nq={nq}: ef={op[0]} recall@10={op[1]:.4f} single-launch qps={op[2]:.0f} alg GB/s={op[3]:.0f} frac={op[3]/8000:.3f}", flush=True)
+else:
+    print(f"OPERATING POINT {which}: recall@10 >= 0.95 not reached inside the sweep", flush=True)
