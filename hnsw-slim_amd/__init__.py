@@ -26,7 +26,7 @@ EXPORTS = [
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
     "hs_search_batch_async", "hs_host_alloc", "hs_host_free", "hs_comm_init", "hs_comm_free", "hs_comm_size", "hs_search_batch_sharded",
-    "hs_comm_results_dev", "hs_convert_slim_gpu",
+    "hs_comm_results_dev", "hs_convert_slim_gpu", "hs_index_patch",
 ]
 
 
@@ -66,6 +66,7 @@ def lib():
     L.hs_device_count.restype = ci
     L.hs_index_load.argtypes = [ctypes.c_char_p, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
     L.hs_index_load_mem.argtypes = [ctypes.c_char_p, sz, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
+    L.hs_index_patch.argtypes = [vp, ctypes.c_char_p, sz, ci]
     L.hs_index_free.argtypes = [vp]
     L.hs_index_free.restype = None
     L.hs_set_ef.argtypes = [vp, sz]
@@ -302,6 +303,11 @@ class Index:
             self.close()
         except Exception:
             pass
+
+    def patch(self, stream_bytes, to_add=False):
+        """patchFromStream: apply a genPatch stream to this device-resident Slim index (loaded with max_elements > count)."""
+        b = bytes(stream_bytes)
+        _check(lib().hs_index_patch(self._h, b, len(b), 1 if to_add else 0))
 
     def info(self):
         i = HsInfo()

@@ -79,6 +79,9 @@ struct hs_index {
   uint32_t user_cand_cap = 0, user_hash_slots = 0;
   uint32_t grow_cand = 0, grow_hash = 0;  // adaptive: doublings learnt from earlier batches' overflow counts
   bool exact_order = false;               // always use the strict kernel (reference output order)
+  // patching (hs_index_patch): a Slim index loaded with max_elements > count keeps its host image and has row capacity
+  std::unique_ptr<SlimGraph> host_slim;
+  size_t cap_rows = 0;
   DevIndex dev{};
   DevBuf<float> vec;
   DevBuf<uint32_t> row_ptr0, cols, up_base, up_ptr, tile0, uptile;
@@ -200,6 +203,13 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   return HS_OK;
 }
 
+template <typename T>
+static hipError_t upload_cap(DevBuf<T> &b, const std::vector<T> &v, size_t cap) {
+  hipError_t e = b.alloc(std::max<size_t>(std::max(v.size(), cap), 1));
+  if (e != hipSuccess) return e;
+  return v.empty() ? hipSuccess : hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
 extern "C" {
 
 const char *hs_last_error(void) { return g_err.c_str(); }
@@ -210,58 +220,47 @@ int hs_device_count(void) {
   return n;
 }
 
-static hs_status upload(hs_index *ix, const PackedIndex &p) {
-  HIP_TRY(hipSetDevice(ix->device));
-  HIP_TRY(ix->vec.upload(p.vec));
-  HIP_TRY(ix->row_ptr0.upload(p.row_ptr0));
-  HIP_TRY(ix->cols.upload(p.cols));
-  HIP_TRY(ix->up_base.upload(p.up_base));
-  HIP_TRY(ix->up_ptr.upload(p.up_ptr));
-  // level-0 adjacency tiles: node i's ids padded with 0xFFFFFFFF to a fixed, 64-byte-multiple stride
-  uint32_t stride = 0;
-  if (p.max_deg0 <= 64) {
-    stride = std::max<uint32_t>(16, (uint32_t)((p.max_deg0 + 15) / 16 * 16));
-    std::vector<uint32_t> tile((size_t)p.n * stride, 0xFFFFFFFFu);
-    for (size_t i = 0; i < p.n; i++)
-      std::copy(p.cols.begin() + p.row_ptr0[i], p.cols.begin() + p.row_ptr0[i + 1], tile.begin() + i * stride);
-    HIP_TRY(ix->tile0.upload(tile));
-  }
-  // upper-level tiles for the greedy descent (see engine.hpp)
-  uint32_t up_stride = 0;
-  {
-    size_t max_up = 0;
-    for (size_t t = 0; t + 1 < p.up_ptr.size(); t++)
-      if (p.up_ptr[t + 1] > p.up_ptr[t]) max_up = std::max<size_t>(max_up, p.up_ptr[t + 1] - p.up_ptr[t]);
-    if (!p.up_ptr.empty() && max_up <= 64) {
-      up_stride = std::max<uint32_t>(16, (uint32_t)((max_up + 15) / 16 * 16));
-      std::vector<uint32_t> ut(p.up_ptr.size() * (size_t)up_stride * 2, 0xFFFFFFFFu);
-      // a node with L upper levels owns L+1 consecutive up_ptr entries (L list starts + one terminator), in id order
-      std::vector<uint32_t> owners;
-      for (size_t i = 0; i < p.n; i++)
-        if (p.up_base[i] != PackedIndex::NONE) owners.push_back((uint32_t)i);
-      for (size_t o = 0; o < owners.size(); o++) {
-        const uint32_t b0 = p.up_base[owners[o]];
-        const uint32_t end = o + 1 < owners.size() ? p.up_base[owners[o + 1]] : (uint32_t)p.up_ptr.size();
-        for (uint32_t t = b0; t + 1 < end; t++) {
-          const uint32_t s0 = p.up_ptr[t], e0 = p.up_ptr[t + 1];
-          for (uint32_t j = 0; j < e0 - s0; j++) {
-            const uint32_t nb = p.cols[s0 + j];
-            ut[((size_t)t * up_stride + j) * 2] = nb;
-            ut[((size_t)t * up_stride + j) * 2 + 1] = p.up_base[nb];
-          }
-        }
+// upper-level tiles for the greedy descent (see engine.hpp): slot t = up_ptr entry t, {neighbour id, the neighbour's up_base}
+static std::vector<uint32_t> build_uptile(const PackedIndex &p, uint32_t &up_stride) {
+  up_stride = 0;
+  std::vector<uint32_t> ut;
+  size_t max_up = 0;
+  for (size_t t = 0; t + 1 < p.up_ptr.size(); t++)
+    if (p.up_ptr[t + 1] > p.up_ptr[t]) max_up = std::max<size_t>(max_up, p.up_ptr[t + 1] - p.up_ptr[t]);
+  if (p.up_ptr.empty() || max_up > 64) return ut;
+  up_stride = std::max<uint32_t>(16, (uint32_t)((max_up + 15) / 16 * 16));
+  ut.assign(p.up_ptr.size() * (size_t)up_stride * 2, 0xFFFFFFFFu);
+  // a node with L upper levels owns L+1 consecutive up_ptr entries (L list starts + one terminator), in id order
+  std::vector<uint32_t> owners;
+  for (size_t i = 0; i < p.n; i++)
+    if (p.up_base[i] != PackedIndex::NONE) owners.push_back((uint32_t)i);
+  for (size_t o = 0; o < owners.size(); o++) {
+    const uint32_t b0 = p.up_base[owners[o]];
+    const uint32_t end = o + 1 < owners.size() ? p.up_base[owners[o + 1]] : (uint32_t)p.up_ptr.size();
+    for (uint32_t t = b0; t + 1 < end; t++) {
+      const uint32_t s0 = p.up_ptr[t], e0 = p.up_ptr[t + 1];
+      for (uint32_t j = 0; j < e0 - s0; j++) {
+        const uint32_t nb = p.cols[s0 + j];
+        ut[((size_t)t * up_stride + j) * 2] = nb;
+        ut[((size_t)t * up_stride + j) * 2 + 1] = p.up_base[nb];
       }
-      HIP_TRY(ix->uptile.upload(ut));
     }
   }
-  HIP_TRY(ix->labels.upload(p.labels));
-  HIP_TRY(ix->deleted.upload(p.deleted));
-  ix->host_labels = p.labels;
-  ix->host_deleted = p.deleted;
+  return ut;
+}
+static uint32_t tile_stride_for(size_t max_deg0) { return max_deg0 <= 64 ? std::max<uint32_t>(16, (uint32_t)((max_deg0 + 15) / 16 * 16)) : 0; }
+
+// the graph-structure arrays that are small next to the vectors and tiles: uploaded whole (also after a patch)
+static hs_status upload_small(hs_index *ix, const PackedIndex &p) {
+  HIP_TRY(ix->row_ptr0.upload(p.row_ptr0));
+  HIP_TRY(ix->cols.upload(p.cols));
+  HIP_TRY(upload_cap(ix->up_base, p.up_base, ix->cap_rows));
+  HIP_TRY(ix->up_ptr.upload(p.up_ptr));
+  uint32_t up_stride = 0;
+  const std::vector<uint32_t> ut = build_uptile(p, up_stride);
+  if (up_stride) HIP_TRY(ix->uptile.upload(ut));
   DevIndex &d = ix->dev;
-  d.vec = ix->vec.p; d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p;
-  d.up_ptr = ix->up_ptr.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
-  d.tile0 = stride ? ix->tile0.p : nullptr; d.tile_stride = stride;
+  d.row_ptr0 = ix->row_ptr0.p; d.cols = ix->cols.p; d.up_base = ix->up_base.p; d.up_ptr = ix->up_ptr.p;
   d.uptile = up_stride ? reinterpret_cast<const uint2 *>(ix->uptile.p) : nullptr; d.up_stride = up_stride;
   d.ep_base = p.n ? p.up_base[p.enterpoint] : 0xFFFFFFFFu;
   d.n = (uint32_t)p.n; d.dim = (uint32_t)p.dim; d.maxlevel = p.maxlevel; d.threshold_level = p.threshold_level;
@@ -271,8 +270,30 @@ static hs_status upload(hs_index *ix, const PackedIndex &p) {
   i.threshold_level = p.threshold_level; i.enterpoint = p.enterpoint; i.has_deleted = p.has_deleted;
   i.n_edges = p.cols.size(); i.max_degree0 = p.max_deg0; i.index_size = p.index_size;
   i.device_bytes = p.vec.size() * 4 + (p.row_ptr0.size() + p.cols.size() + p.up_base.size() + p.up_ptr.size()) * 4 +
-                   p.labels.size() * 8 + p.deleted.size() + (size_t)p.n * stride * 4;
+                   p.labels.size() * 8 + p.deleted.size() + (size_t)p.n * ix->dev.tile_stride * 4;
   return HS_OK;
+}
+
+static hs_status upload(hs_index *ix, const PackedIndex &p) {
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t cap = std::max(ix->cap_rows, p.n);
+  HIP_TRY(upload_cap(ix->vec, p.vec, cap * p.dim));
+  // level-0 adjacency tiles: node i's ids padded with 0xFFFFFFFF to a fixed, 64-byte-multiple stride
+  const uint32_t stride = tile_stride_for(p.max_deg0);
+  if (stride) {
+    std::vector<uint32_t> tile((size_t)p.n * stride, 0xFFFFFFFFu);
+    for (size_t i = 0; i < p.n; i++)
+      std::copy(p.cols.begin() + p.row_ptr0[i], p.cols.begin() + p.row_ptr0[i + 1], tile.begin() + i * stride);
+    HIP_TRY(upload_cap(ix->tile0, tile, cap * stride));
+  }
+  HIP_TRY(upload_cap(ix->labels, p.labels, cap));
+  HIP_TRY(upload_cap(ix->deleted, p.deleted, cap));
+  ix->host_labels = p.labels;
+  ix->host_deleted = p.deleted;
+  DevIndex &d = ix->dev;
+  d.vec = ix->vec.p; d.labels = ix->labels.p; d.deleted = ix->deleted.p;
+  d.tile0 = stride ? ix->tile0.p : nullptr; d.tile_stride = stride;
+  return upload_small(ix, p);
 }
 
 // HierarchicalNSWSlimQ::loadIndex (hnswalg_slimq.h:1218-1313): graph -> CSR/tiles, element records -> 16-byte header
@@ -384,15 +405,17 @@ static hs_status load_from(const BinSource &src, int kind, int metric, size_t di
   if (dim == 0) return fail(HS_ERR_INVALID, "dim must be > 0");
   if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
   PackedIndex p;
+  std::unique_ptr<SlimGraph> keep_slim;
   try {
     if (kind == HS_KIND_HNSW) {
       VanillaGraph g;
       g.load(src, (Metric)metric, dim, max_elements);
       p.from_vanilla(g);
     } else if (kind == HS_KIND_SLIM) {
-      SlimGraph g;
-      g.load(src, (Metric)metric, dim);
-      p.from_slim(g);
+      std::unique_ptr<SlimGraph> g(new SlimGraph());
+      g->load(src, (Metric)metric, dim);
+      p.from_slim(*g);
+      if (max_elements > g->count) keep_slim = std::move(g);   // room for patchFromStream (hnswalg_slim.h:760, 784)
     } else if (kind == HS_KIND_SLIMQ) {
       return load_slimq(src, metric, dim, device, out);
     } else {
@@ -405,10 +428,88 @@ static hs_status load_from(const BinSource &src, int kind, int metric, size_t di
   }
   hs_index *ix = new hs_index();
   ix->device = device;
+  if (keep_slim) { ix->cap_rows = max_elements; ix->host_slim = std::move(keep_slim); }
   hs_status s = upload(ix, p);
   if (s != HS_OK) { delete ix; return s; }
   *out = ix;
   return HS_OK;
+}
+
+// patchFromStream(std::istream &in, bool to_add) (hnswalg_slim.h:2292-2340) on a device-resident index.  Stream, as the
+// reference's server assembles it (hnsw_slim_server_patch.cc:280-290 after its `finished` word; records by genPatch,
+// hnswalg_slim.h:1427-1476):  u64 cur_element_count, u64 changed_old_cnt, u64 changed_new_cnt, then per changed node
+//   u32 id | old node: 8 bytes {i32 level, u32 total_neighbor}; new node: 16 bytes {level, total, u64 label} |
+//   u32 neighborsSize | the neighbour blob | new node and to_add: data_size bytes of vector.
+// The host image takes the records exactly as the reference's does; on the device the two big arrays (vectors, level-0
+// tiles) are rewritten only where a node changed, the small structure arrays (CSR, upper-level tiles) are rebuilt whole.
+// As in the reference the stream carries no enter point / max level: they stay what they were.
+hs_status hs_index_patch(hs_index *ix, const void *bytes, size_t len, int to_add) {
+  if (!ix || !bytes) return fail(HS_ERR_INVALID, "null argument");
+  if (!ix->host_slim) return fail(HS_ERR_INVALID, "index not patchable: load a Slim index with max_elements > its element count");
+  SlimGraph &g = *ix->host_slim;
+  const size_t spe = g.size_per_el, dim = g.dim;
+  std::vector<uint32_t> changed;
+  size_t new_count = 0;
+  try {
+    BinReader r(BinSource(bytes, len));
+    new_count = r.pod<uint64_t>();
+    const uint64_t n_old = r.pod<uint64_t>(), n_new = r.pod<uint64_t>();
+    if (new_count > ix->cap_rows || new_count < g.count || n_old + n_new > (1ull << 32)) return fail(HS_ERR_CAPACITY, "patch exceeds max_elements");
+    // stage the records first: a malformed stream must leave the index untouched
+    struct Rec { uint32_t id; char head[16]; std::vector<char> blob; std::vector<char> vec; bool is_new; };
+    std::vector<Rec> recs((size_t)(n_old + n_new));
+    for (size_t i = 0; i < recs.size(); i++) {
+      Rec &rc = recs[i];
+      rc.is_new = i >= n_old;
+      rc.id = r.pod<uint32_t>();
+      r.bytes(rc.head, rc.is_new ? 16 : 8);
+      const uint32_t nsz = r.pod<uint32_t>();
+      int32_t level; uint32_t total;
+      memcpy(&level, rc.head, 4); memcpy(&total, rc.head + 4, 4);
+      if (rc.id >= new_count || level < 0 || level > 64 || (nsz != 0 && nsz != 2 * (uint32_t)level + 4 * total))
+        return fail(HS_ERR_CORRUPT, "Index seems to be corrupted or unsupported");
+      rc.blob.resize(nsz);
+      if (nsz) r.bytes(rc.blob.data(), nsz);
+      if (to_add && rc.is_new) { rc.vec.resize(dim * 4); r.bytes(rc.vec.data(), dim * 4); }
+    }
+    g.elements.resize(new_count * spe, 0);
+    g.blobs.resize(new_count);
+    for (Rec &rc : recs) {
+      char *e = g.elements.data() + (size_t)rc.id * spe;
+      memcpy(e, rc.head, rc.is_new ? 16 : 8);
+      uint32_t total; memcpy(&total, e + 4, 4);
+      g.blobs[rc.id] = (rc.blob.empty() || total == 0) ? std::vector<char>() : std::move(rc.blob);
+      if (!rc.vec.empty()) memcpy(e + 24, rc.vec.data(), dim * 4);
+      changed.push_back(rc.id);
+    }
+    g.count = new_count;
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory: patchFromStream failed to allocate linklist");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  PackedIndex p;
+  try {
+    p.from_slim(g);
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipDeviceSynchronize());   // no search may be in flight on this index while it is rewritten
+  const uint32_t stride = tile_stride_for(p.max_deg0);
+  if (stride != ix->dev.tile_stride || !ix->dev.tile0) return upload(ix, p);   // a list outgrew the tile stride: re-tile everything
+  std::vector<uint32_t> row(stride);
+  for (uint32_t id : changed) {
+    std::fill(row.begin(), row.end(), 0xFFFFFFFFu);
+    std::copy(p.cols.begin() + p.row_ptr0[id], p.cols.begin() + p.row_ptr0[id + 1], row.begin());
+    HIP_TRY(hipMemcpy(ix->tile0.p + (size_t)id * stride, row.data(), stride * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->vec.p + (size_t)id * dim, &p.vec[(size_t)id * dim], dim * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->labels.p + id, &p.labels[id], 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->deleted.p + id, &p.deleted[id], 1, hipMemcpyHostToDevice));
+  }
+  ix->host_labels = p.labels;
+  ix->host_deleted = p.deleted;
+  return upload_small(ix, p);
 }
 
 hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements, int device,

@@ -126,12 +126,25 @@ __device__ __forceinline__ float quad_dist4(const float *q, const float *x, uint
   return METRIC == METRIC_L2 ? r : 1.0f - r;
 }
 
+// One 16-byte chunk of the row against the query chunk: acc[j] (+)= contribution of elements j < 4, as two packed-f32 halves.
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do two lanes of the recipe per issue slot with the same IEEE rounding per element
+// (a rounded subtract, a rounded multiply, a rounded add for L2 -- never fused; one fused multiply-add for IP), so the values are
+// those of dist_recipe.hpp's l2_step4 / ip_step4 bit for bit and the distance arithmetic costs half the vector-issue slots.
+typedef float hs_f2 __attribute__((ext_vector_type(2)));
 template <int METRIC>
 __device__ __forceinline__ void step4(float (&acc)[4], const float4 &q4, const float4 &x4) {
-  const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-  const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-  if (METRIC == METRIC_L2) l2_step4(acc, q, x);
-  else ip_step4(acc, q, x);
+  hs_f2 a0 = {acc[0], acc[1]}, a1 = {acc[2], acc[3]};
+  const hs_f2 q0 = {q4.x, q4.y}, q1 = {q4.z, q4.w}, x0 = {x4.x, x4.y}, x1 = {x4.z, x4.w};
+  if (METRIC == METRIC_L2) {
+    const hs_f2 t0 = q0 - x0, t1 = q1 - x1;
+    const hs_f2 p0 = t0 * t0, p1 = t1 * t1;
+    a0 = a0 + p0;
+    a1 = a1 + p1;
+  } else {
+    a0 = __builtin_elementwise_fma(q0, x0, a0);
+    a1 = __builtin_elementwise_fma(q1, x1, a1);
+  }
+  acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
 }
 
 

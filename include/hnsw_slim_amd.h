@@ -75,6 +75,14 @@ hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size
  * (hnsw_slim_server.cc:59-81) or keep it in a buffer; nothing is written to disk.  The bytes are not retained. */
 hs_status hs_index_load_mem(const void *bytes, size_t len, int kind, int metric, size_t dim, size_t max_elements,
                             int device, hs_index **out);
+/* patchFromStream(std::istream&, bool to_add): hnswalg_slim.h:2292-2340, wire format of genPatch :1427-1476 as the reference's
+ * server frames it (hnsw_slim_server_patch.cc:280-290, after its `finished` word): u64 cur_element_count, u64 changed_old_cnt,
+ * u64 changed_new_cnt, then per changed node  u32 id | 8 B {level, total_neighbor} (old node) or 16 B {level, total, label}
+ * (new node) | u32 neighborsSize | blob | the vector (new node, to_add).  Applies to a HS_KIND_SLIM index that was loaded with
+ * max_elements > its element count (the reference needs the same room, hnswalg_slim.h:784).  Only the changed nodes' rows of the
+ * vectors and level-0 tiles are rewritten in HBM; the small structure arrays are rebuilt.  Like the reference, the stream
+ * does not move the enter point.  Not to be called while a search on this index is in flight. */
+hs_status hs_index_patch(hs_index *ix, const void *bytes, size_t len, int to_add);
 void hs_index_free(hs_index *ix);                        /* ~HierarchicalNSW* / clear(): hnswalg_slim.h:154-167 */
 hs_status hs_set_ef(hs_index *ix, size_t ef);            /* setEf: hnswalg.h:184, hnswalg_slim.h:193 */
 hs_status hs_index_info(const hs_index *ix, hs_info *out);

@@ -184,3 +184,50 @@ def write_slimq(g, garbage_seed=777):
         if b:
             out.append(b)
     return b"".join(out)
+
+
+# ---- the diff / patch wire format (genPatch hnswalg_slim.h:1427-1476, framed as hnsw_slim_server_patch.cc:280-290 does) ------
+def make_patch(raw_old, raw_new, dim, to_add=True):
+    """Patch stream that turns Slim file `raw_old` (n nodes) into `raw_new` (n + delta nodes, the first n being the same points):
+    u64 cur_element_count, u64 changed_old_cnt, u64 changed_new_cnt, then the changed old nodes (8-byte head) and the new nodes
+    (16-byte head, + vector when to_add).  Test infrastructure: the reference derives the changed sets in
+    convertFromHNSWWithDiff; here they come from comparing the two files."""
+    a, b = parse_slim(raw_old, dim), parse_slim(raw_new, dim)
+    n_old, n_new = a["count"], b["count"]
+    assert n_new >= n_old
+
+    def blob(g, i):
+        node = g["lists"][i]
+        level = len(node) - 1
+        total = int(sum(len(x) for x in node))
+        cum = np.cumsum([len(x) for x in node])[:level].astype(np.uint16)
+        return level, total, (cum.tobytes() + (np.concatenate(node).astype(np.uint32).tobytes() if total else b""))
+
+    old_ids = []
+    for i in range(n_old):
+        la, lb = a["lists"][i], b["lists"][i]
+        if len(la) != len(lb) or any(not np.array_equal(x, y) for x, y in zip(la, lb)):
+            old_ids.append(i)
+    out = [struct.pack("<3Q", n_new, len(old_ids), n_new - n_old)]
+    for i in old_ids:
+        level, total, bl = blob(b, i)
+        out.append(struct.pack("<IiI", i, level, total))
+        out.append(struct.pack("<I", len(bl) if total else 0))
+        if total:
+            out.append(bl)
+    for i in range(n_old, n_new):
+        level, total, bl = blob(b, i)
+        out.append(struct.pack("<IiIQ", i, level, total, int(b["labels"][i])))
+        out.append(struct.pack("<I", len(bl) if total else 0))
+        if total:
+            out.append(bl)
+        if to_add:
+            out.append(np.ascontiguousarray(b["rows"][i], np.float32).tobytes())
+    return b"".join(out), len(old_ids), n_new - n_old
+
+
+def with_entry_of(raw_new, raw_old):
+    """`raw_new` with the enter point and max level of `raw_old` (the patch stream does not carry them: hnswalg_slim.h:2292-2340)."""
+    h_old, h_new = list(struct.unpack_from(SLIM_HDR, raw_old, 0)), list(struct.unpack_from(SLIM_HDR, raw_new, 0))
+    h_new[6], h_new[8] = h_old[6], h_old[8]
+    return struct.pack(SLIM_HDR, *h_new) + raw_new[struct.calcsize(SLIM_HDR):]
