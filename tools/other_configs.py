@@ -17,7 +17,7 @@ if which == "gist":
     gen = lambda m, seed: np.clip(sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False) / 255.0, 0, 1).astype(np.float32)
 else:
     n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000, int(os.environ.get("DIM", "96")), 10000
-    G = [float(x) for x in os.environ.get("GEN", "32768,12,40,2").split(",")]
+    G = [float(x) for x in os.environ.get("GEN", "32768,12,40,4")   # calibrated in round 2 (profiles/r02_cfg_deep10m_d96.log).split(",")]
     def gen(m, seed):
         x = sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
@@ -36,7 +36,7 @@ gt = ground_truth(torch, bt, qt, 10, hs); del bt
 lab = torch.empty((nq, 10), dtype=torch.int32, device=dev); cnt = torch.empty((nq,), dtype=torch.int32, device=dev); st = torch.empty((nq, 4), dtype=torch.int32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 op = None
-for ef in [int(e) for e in os.environ.get('EFS', '32,64,128,256,384,512').split(',')]:
+for ef in [int(e) for e in os.environ.get('EFS', '32,64,128,192,256,384,512').split(',')]:
     ix.set_ef(ef); ox.set_ef(ef)
     for _ in range(2):
         ix.search_ids_dev(qt, 10, lab, None, cnt, st, s); ix.check(s)

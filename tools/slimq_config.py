@@ -18,7 +18,10 @@ if which == "sift":
 else:
     n, d, nq, metric = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 768, 10000, 1
     def gen(m, seed):
-        x = sift_like(m, d, seed, n_clusters=4096, rank=12, sigma_sub=40.0, sigma_iso=1.0, integer=False, centre_lo=-60, centre_hi=60)
+        # round-2 calibration (profiles/r02_calib_cohere_local.log): 256 components of rank 24 keep both the pruned graph and the
+        # 1-bit estimates usable; GEN = n_clusters,rank,sigma_sub,sigma_iso,centre_half_width
+        G = [float(v) for v in os.environ.get("GEN", "256,24,40,1.5,40").split(",")]
+        x = sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False, centre_lo=-G[4], centre_hi=G[4])
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
 t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
 dev = torch.device("cuda", 0)
@@ -43,9 +46,10 @@ for _ in range(8):
 cen = cen.cpu().numpy(); del samp, bt
 with tempfile.TemporaryDirectory() as tmp:
     hp, sp, qp = (os.path.join(tmp, f) for f in ("h.bin", "s.bin", "q.bin"))
-    t0 = time.time(); hs.build_hnsw(base, hp, metric=metric, M=16, ef_construction=200, threads=64); tb = time.time() - t0
-    t0 = time.time(); hs.convert_slim(hp, sp, d, metric=metric, threads=64); tc = time.time() - t0
-    t0 = time.time(); hs.convert_slimq(sp, metric, d, cen, qp, threads=64); tq = time.time() - t0
+    thr = min(len(os.sched_getaffinity(0)), 64)
+    t0 = time.time(); hs.build_hnsw(base, hp, metric=metric, M=16, ef_construction=200, threads=thr); tb = time.time() - t0
+    t0 = time.time(); hs.convert_slim(hp, sp, d, metric=metric, threads=thr); tc = time.time() - t0
+    t0 = time.time(); hs.convert_slimq(sp, metric, d, cen, qp, threads=thr); tq = time.time() - t0
     print(f"build {tb:.0f}s convert {tc:.0f}s quantise {tq:.0f}s  slim {os.path.getsize(sp)/1e6:.0f} MB slimq {os.path.getsize(qp)/1e6:.0f} MB", flush=True)
     ix = hs.Index(qp, hs.HS_KIND_SLIMQ, d, metric=metric)
     ox = Oracle().load_slimq(qp)
@@ -65,7 +69,7 @@ s = torch.cuda.current_stream().cuda_stream
 streams = [torch.cuda.Stream() for _ in range(4)]
 outs = [(torch.empty_like(lab), torch.empty_like(dd), torch.empty_like(cnt)) for _ in range(4)]
 rec_bytes = 16 + (d + 63) // 64 * 8
-for ef in [int(e) for e in os.environ.get("EFS", "32,64,96,128,192,256,384,512").split(",")]:
+for ef in [int(e) for e in os.environ.get("EFS", "64,128,256,512,1024").split(",")]:
     ix.set_ef(ef); ox.set(ef, ix.slimq_tconst(), base)
     for _ in range(2):
         ix.slimq_search_dev(qt, 10, lab, dd, cnt, st, s); ix.check(s)
