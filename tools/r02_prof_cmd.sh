@@ -2,6 +2,8 @@
 # kernel-trace stats of both, PMC passes for HBM traffic and the instruction mix (separate --pmc runs, as the guide asks), the
 # gather calibration of FETCH_SIZE, and the 1M-node convertFromHNSW timing (CPU harness vs GPU).
 set -x
+( while true; do sleep 60; date >> gpurun_out/heartbeat.log; done ) &
+HB=$!
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r02
@@ -22,4 +24,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib -- /tmp/gather_ca
 python tools/convert_bench.py /tmp/idx/hnsw.bin 128 > $O/convert_1m.log 2>&1
 find $O -name "*agent_info.csv" -delete
 find $O -name "*kernel_trace.csv" -size +20M -delete
+kill $HB
 echo EF=$EF
