@@ -53,6 +53,7 @@ struct SearchArgs {
   uint32_t *counters;    // [0] visited-set overflows, [1] candidate-heap overflows, [2] tie hazards, [3] tier-2 spills (this pass)
   uint32_t pass_id;
   uint32_t *queue;       // group kernel: device-wide query counter (zeroed per launch group)
+  uint32_t hash_fill_shift;   // visited-set tier 1 is frozen at 1 - 2^-shift of its slots (0 = the default 2: 75 %)
 };
 
 // Bytes of dynamic LDS one query (one wavefront) needs.
