@@ -131,6 +131,13 @@ struct Counters {
 // `between()` runs after the first pass's row loads have been ISSUED and before they are
 // consumed: LDS-only work placed there (the candidate heap's pop) hides under the HBM latency.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// Loads in flight per lane and round for a compile-time dim.  Up to d = 128 the whole row; long rows (d >= 256: 1 KB and more per
+// row) take 16 loads per round instead of 8 -- a hop over 3.8 KB rows (d = 960) is then 4 dependent load rounds instead of 8;
+// those instantiations run at 2 wavefronts per SIMD (256 VGPRs), which is no loss where the bytes per hop, not the number of
+// resident queries, set the pace.
+__host__ __device__ constexpr int deep_buffer(int d16) {
+  return d16 <= 0 ? 1 : d16 <= 8 ? d16 : d16 == 32 ? 32 : 16;   // (the query chunks of a round are read from LDS into registers too: 8 VGPRs per load)
+}
 
 // TO_REG: instead of writing nd[j], hand the value of row j to lane j in a register (one cross-lane move,
 // no LDS write/read round trip); returned value is meaningful in lanes < cnt.
@@ -164,6 +171,72 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
     }
     return out;
   }
+  if (D16 > 8) {
+    // Long rows (d >= 256, compile-time dim): 8 lanes per row, 8 rows per pass.  A hop brings ~6 new rows; with 4 lanes per row
+    // they occupy 24 of the 64 lanes and a 3.8 KB row (d = 960) takes four dependent load rounds, with 8 lanes per row 48 lanes
+    // are busy and it takes two.  Lane s8 of a group owns AVX-512 lane accumulators 2 s8, 2 s8 + 1 and loads the 8 bytes at
+    // 64 i + 8 s8 of every 64-byte step i, so every accumulator still sums its elements in the reference's order, and the
+    // sixteen are combined in the reference's order (left to right for L2, space_l2.h:49-51; the halves tree of
+    // _mm512_reduce_add_ps for IP, space_ip.h:197).
+    const int s8 = lane & 7, g8 = lane >> 3;
+    constexpr int B8 = D16 <= 32 ? (D16 > 0 ? D16 : 1) : (D16 % 30 == 0 ? 30 : D16 % 32 == 0 ? 32 : D16 % 24 == 0 ? 24 : 16);
+    constexpr int R8 = (D16 > 0 ? D16 : 1) / B8, T8 = (D16 > 0 ? D16 : 1) % B8;
+    const hs_f2 *q2 = reinterpret_cast<const hs_f2 *>(qv) + s8;
+    for (uint32_t base = 0; base < cnt; base += 8) {
+      const uint32_t j = base + g8;
+      const bool act = j < cnt;
+      const uint32_t id = nid[act ? j : base];   // idle groups re-read the pass's first row (cache hit) and discard
+      const hs_f2 *row = reinterpret_cast<const hs_f2 *>(ix.vec + (size_t)id * (D16 * 16)) + s8;
+      hs_f2 acc2 = {0.f, 0.f};
+      hs_f2 buf[B8];
+#pragma unroll 1
+      for (int r = 0; r < R8; r++) {
+#pragma unroll
+        for (int i = 0; i < B8; i++) buf[i] = row[(r * B8 + i) * 8];
+        if (base == 0 && r == 0) between();
+#pragma unroll
+        for (int i = 0; i < B8; i++) {
+          const hs_f2 qe = q2[(r * B8 + i) * 8];
+          if (METRIC == METRIC_L2) { const hs_f2 t = qe - buf[i]; const hs_f2 pp = t * t; acc2 = acc2 + pp; }
+          else acc2 = __builtin_elementwise_fma(qe, buf[i], acc2);
+        }
+      }
+      if (T8 > 0) {
+#pragma unroll
+        for (int i = 0; i < T8; i++) buf[i] = row[(R8 * B8 + i) * 8];
+#pragma unroll
+        for (int i = 0; i < T8; i++) {
+          const hs_f2 qe = q2[(R8 * B8 + i) * 8];
+          if (METRIC == METRIC_L2) { const hs_f2 t = qe - buf[i]; const hs_f2 pp = t * t; acc2 = acc2 + pp; }
+          else acc2 = __builtin_elementwise_fma(qe, buf[i], acc2);
+        }
+      }
+      float r;
+      int own;
+      if (METRIC == METRIC_L2) {
+        r = acc2.x + acc2.y;
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+          const float p = dpp_f<0x111>(r);   // row_shr:1 -- the running sum of the lane to the left (same 8-lane group)
+          if (s8 == k) r = (p + acc2.x) + acc2.y;
+        }
+        own = 7;
+      } else {
+        float hx = acc2.x + dpp_f<0x104>(acc2.x), hy = acc2.y + dpp_f<0x104>(acc2.y);   // row_shl:4: accumulators j + 8
+        hx = hx + dpp_f<0x102>(hx); hy = hy + dpp_f<0x102>(hy);                          // j + 4
+        hx = hx + dpp_f<0x101>(hx); hy = hy + dpp_f<0x101>(hy);                          // j + 2
+        r = 1.0f - (hx + hy);
+        own = 0;
+      }
+      if (TO_REG) {
+        const float got = __shfl(r, ((lane - (int)base) & 7) * 8 + own, 64);
+        if ((uint32_t)lane >= base && (uint32_t)lane < base + 8 && (uint32_t)lane < cnt) out = got;
+      } else {
+        if (act && s8 == own) nd[j] = r;
+      }
+    }
+    return out;
+  }
   const float4 *qq = reinterpret_cast<const float4 *>(qv) + sub;
   for (uint32_t base = 0; base < cnt; base += 16) {
     const uint32_t j = base + grp;
@@ -173,7 +246,7 @@ __device__ __forceinline__ float wave_dists(const DevIndex &ix, const float *qv,
     if (D16 > 0) {
       // compile-time dim: rounds of up to eight 16-byte loads per lane in flight, then the arithmetic of the round
       const float4 *row = reinterpret_cast<const float4 *>(ix.vec + (size_t)id * (D16 * 16)) + sub;
-      constexpr int B = D16 <= 0 ? 1 : (D16 <= 8 ? D16 : 8);   // (D16 == 0 instantiates this branch too, dead)
+      constexpr int B = deep_buffer(D16);   // loads in flight per lane (D16 == 0 instantiates this branch too, dead)
       constexpr int R = D16 / B, T = D16 % B;                  // full rounds, tail
       float4 buf[B];
 #pragma unroll
@@ -898,7 +971,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
 #define HS_FAST_WAVES 4
 #endif
 template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_FAST_WAVES))) fast_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D16 > 16 ? 3 : HS_FAST_WAVES))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
     if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;  // pass 0 takes every query

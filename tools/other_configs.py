@@ -17,7 +17,7 @@ if which == "gist":
     gen = lambda m, seed: np.clip(sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False) / 255.0, 0, 1).astype(np.float32)
 else:
     n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000, int(os.environ.get("DIM", "96")), 10000
-    G = [float(x) for x in os.environ.get("GEN", "32768,12,40,4")   # calibrated in round 2 (profiles/r02_cfg_deep10m_d96.log).split(",")]
+    G = [float(x) for x in os.environ.get("GEN", "32768,12,40,4").split(",")]   # calibrated in round 2 (profiles/r02_cfg_deep10m_d96.log)
     def gen(m, seed):
         x = sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
