@@ -134,9 +134,12 @@ static uint32_t next_pow2(uint32_t v) {
 struct Shape {
   uint32_t ef, cand_cap, cand_cap_fast, hash_slots;
   uint32_t g_cand_cap, g_hash_slots;    // group kernel (four queries per wavefront): per-query LDS shares
+  uint32_t l_cand_cap, l_hash_slots;    // lean kernel
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
+static constexpr uint32_t kLeanMinEf = 192;   // from here upwards the lean kernel (keys-only result set, smaller LDS share) is the faster one:
+                                              // +11 % single launch / +15 % steady state at ef=256, -7 % / +5 % at 128, slower below (profiles/r02_lean_kernel_experiment.log)
 static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
 static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
 static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)
@@ -185,6 +188,14 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
     }
     s.g_cand_cap = gc;
     s.g_hash_slots = gh;
+  }
+  // Lean kernel (large ef): candidate heap ~p99 of its peak size, visited set ~p90 of the distance evaluations at an 87.5 % fill
+  // limit (measured on the 1M SIFT-like bench index, ef 32..256); the rest continue in their tier-2 regions.
+  {
+    uint32_t lc = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((2.5 * ef + 130) * (1u << ix->grow_cand));
+    s.l_cand_cap = std::max<uint32_t>((lc + 1) & ~1u, 16);
+    const uint32_t lh = ix->user_hash_slots ? ix->user_hash_slots : (uint32_t)((520 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash) / 0.875);
+    s.l_hash_slots = (lh + 63) / 64 * 64;
   }
   // shrink the first-pass shape if it does not fit one CU at all
   while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.hash_slots > 256) s.hash_slots >>= 1;
@@ -596,9 +607,19 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   static const bool use_group = getenv("HS_GROUP") != nullptr;
   const bool group = use_group && !ix->exact_order && !raw && group_supported(ix->dev, sh.ef, (uint32_t)k) &&
                      group_lds_bytes((uint32_t)ix->info.dim, sh.g_cand_cap, sh.g_hash_slots, group_q_in_regs(ix->info.metric, (uint32_t)ix->info.dim)) <= kLdsPerCU;
+  // The lean kernel answers from HS_LEAN_MIN_EF upwards (diagnostic knob; default: see kLeanMinEf)
+  static const uint32_t lean_min_ef = getenv("HS_LEAN_MIN_EF") ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
+  const bool lean = !group && fast && sh.ef >= lean_min_ef && lean_supported(ix->dev, sh.ef, (uint32_t)k) &&
+                    lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.l_hash_slots) <= kLdsPerCU;
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
-  if (group) {
+  if (lean) {
+    // pass 0: the lean kernel; a query that exhausts even its tier-2 regions is left ST_OVERFLOW for the passes below
+    a.cand_cap = sh.l_cand_cap; a.hash_slots = sh.l_hash_slots; a.hash_fill_shift = 3;
+    a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
+    HIP_TRY(launch_lean(ix->dev, a, stream));
+    a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.hash_fill_shift = 0;
+  } else if (group) {
     // pass 0: the group kernel (four queries per wavefront, persistent grid) answers every query; one whose scratch runs
     // out even in its tier-2 regions is left ST_OVERFLOW for the one-query-per-wave kernels below
     a.cand_cap = sh.g_cand_cap; a.hash_slots = sh.g_hash_slots;
@@ -618,7 +639,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
   }
   // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
-  if (fast || group) {
+  if (fast || group || lean) {
     a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
     a.counters = w->counters.p + 4; a.pass_id = 1;
     HIP_TRY(launch_strict(ix->dev, a, stream));

@@ -66,6 +66,10 @@ bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 // output order.  Fast kernel: same traversal and candidate mechanics, result set kept as a sorted
 // register array; queries whose answer could depend on the result heap's layout are flagged ST_HAZARD.
 hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+// Lean kernel (lean_search.hip): the fast kernel's algorithm with a keys-only result set (no ids, no LDS staging of the merge).
+bool lean_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
+size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
+hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 // Group kernel (group_search.hip): four queries per wavefront, persistent grid; same contract as the fast kernel.
 bool group_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 bool group_q_in_regs(int metric, uint32_t dim);

@@ -452,7 +452,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
 }
 
 #ifndef HS_LEAN_WAVES
-#define HS_LEAN_WAVES 6
+#define HS_LEAN_WAVES 4
 #endif
 template <int METRIC, int S, int D16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_LEAN_WAVES))) lean_kernel(DevIndex ix, SearchArgs a) {
@@ -493,7 +493,6 @@ bool lean_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
          (ix.dim & 15u) == 0 && ef >= k && ef <= 256 && k <= 64;
 }
 size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) { return lean_layout(dim, ef, cand_cap, hash_slots).total; }
-int lean_waves_per_simd() { return HS_LEAN_WAVES; }
 hipError_t launch_lean_l2(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) { return lean_launch_s<METRIC_L2>(ix, a, stream); }
 hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
   return ix.metric == METRIC_L2 ? launch_lean_l2(ix, a, stream) : launch_lean_ip(ix, a, stream);

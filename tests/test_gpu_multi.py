@@ -157,8 +157,9 @@ def test_two_rank_processes_drive_the_device_entry(hs, slim_file, tmp_path, nq):
 
 
 def test_group_kernel_parity_under_env(hs, tmp_path):
-    """The four-queries-per-wavefront kernel (group_search.hip; HS_GROUP=1, off by default because it measured slower):
-    same labels, distances and counters as the default kernel on tie-heavy integer data and on a tie-free graph, with
+    """The four-queries-per-wavefront kernel (group_search.hip; HS_GROUP=1, off by default because it measured slower) and the lean
+    kernel (lean_search.hip; serves ef >= 192 by default, forced for every ef here):
+    same labels, distances and counters as the fast kernel on tie-heavy integer data and on a tie-free graph, with
     starved scratch (tier-2 visited set / candidate heap) as well."""
     code = r'''
 import os, sys, numpy as np
@@ -182,9 +183,10 @@ np.savez(sys.argv[3], **out)
     hs.build_hnsw(base, str(tmp_path / "h.bin"), M=16, ef_construction=100, threads=8)
     hs.convert_slim(str(tmp_path / "h.bin"), str(tmp_path / "s.bin"), 128, threads=8)
     res = {}
-    for tag, env in (("fast", {}), ("group", {"HS_GROUP": "1"})):
+    for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000"}), ("group", {"HS_GROUP": "1"}), ("lean", {"HS_LEAN_MIN_EF": "1"})):
         of = str(tmp_path / f"{tag}.npz")
         subprocess.check_call([sys.executable, wf, ROOT, str(tmp_path), of], env=dict(os.environ, **env))
         res[tag] = np.load(of)
     for key in res["fast"].files:
         assert np.array_equal(res["fast"][key], res["group"][key]), key
+        assert np.array_equal(res["fast"][key], res["lean"][key]), key
