@@ -26,7 +26,7 @@ EXPORTS = [
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
     "hs_search_batch_async", "hs_host_alloc", "hs_host_free", "hs_comm_init", "hs_comm_free", "hs_comm_size", "hs_search_batch_sharded",
-    "hs_comm_results_dev", "hs_convert_slim_gpu", "hs_index_patch",
+    "hs_comm_results_dev", "hs_convert_slim_gpu", "hs_index_patch", "hs_index_from_host_arrays",
 ]
 
 
@@ -67,6 +67,7 @@ def lib():
     L.hs_index_load.argtypes = [ctypes.c_char_p, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
     L.hs_index_load_mem.argtypes = [ctypes.c_char_p, sz, ci, ci, sz, sz, ci, ctypes.POINTER(vp)]
     L.hs_index_patch.argtypes = [vp, ctypes.c_char_p, sz, ci]
+    L.hs_index_from_host_arrays.argtypes = [ci, ci, sz, sz, vp, vp, vp, vp, vp, vp, u32, ctypes.c_int32, ctypes.c_int32, ci, ctypes.POINTER(vp)]
     L.hs_index_free.argtypes = [vp]
     L.hs_index_free.restype = None
     L.hs_set_ef.argtypes = [vp, sz]
@@ -292,6 +293,26 @@ class Index:
             _check(lib().hs_index_load_mem(buf, len(buf), kind, metric, dim, max_elements, device, ctypes.byref(self._h)))
         else:
             _check(lib().hs_index_load(path.encode(), kind, metric, dim, max_elements, device, ctypes.byref(self._h)))
+
+    @classmethod
+    def from_arrays(cls, kind, metric, vectors, levels, lists, enterpoint, maxlevel, labels=None, deleted=None, threshold_level=0, device=0):
+        """hs_index_from_host_arrays: lists[i][l] = neighbour ids of node i at level l (l = 0..levels[i])."""
+        v = np.ascontiguousarray(vectors, np.float32)
+        n, dim = v.shape
+        lv = np.ascontiguousarray(levels, np.int32)
+        flat = [np.asarray(l, np.uint32) for node in lists for l in node]
+        ptr = np.zeros(len(flat) + 1, np.uint64)
+        ptr[1:] = np.cumsum([len(x) for x in flat])
+        ids = np.ascontiguousarray(np.concatenate(flat) if flat else np.zeros(0, np.uint32), np.uint32)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint64)
+        dl = None if deleted is None else np.ascontiguousarray(deleted, np.uint8)
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.kind, self.dim, self.metric, self.device, self.ef = kind, dim, metric, device, 10
+        _check(lib().hs_index_from_host_arrays(kind, metric, n, dim, v.ctypes.data, None if lab is None else lab.ctypes.data,
+                                               None if dl is None else dl.ctypes.data, lv.ctypes.data, ptr.ctypes.data, ids.ctypes.data,
+                                               int(enterpoint), int(maxlevel), int(threshold_level), device, ctypes.byref(self._h)))
+        return self
 
     def close(self):
         if self._h:

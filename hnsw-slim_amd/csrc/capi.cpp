@@ -523,6 +523,74 @@ hs_status hs_index_patch(hs_index *ix, const void *bytes, size_t len, int to_add
   return upload_small(ix, p);
 }
 
+// An index the host has already parsed: node i owns levels[i] + 1 consecutive neighbour lists (level 0 first),
+// list t = list_ids[list_ptr[t] .. list_ptr[t+1]).  kind selects the searchKnn semantics (HS_KIND_HNSW / HS_KIND_SLIM).
+hs_status hs_index_from_host_arrays(int kind, int metric, size_t n, size_t dim, const float *vectors, const uint64_t *labels,
+                                    const uint8_t *deleted, const int32_t *levels, const uint64_t *list_ptr, const uint32_t *list_ids,
+                                    uint32_t enterpoint, int32_t maxlevel, int32_t threshold_level, int device, hs_index **out) {
+  if (!out || (n && (!vectors || !levels || !list_ptr || !list_ids))) return fail(HS_ERR_INVALID, "null argument");
+  if (kind != HS_KIND_HNSW && kind != HS_KIND_SLIM) return fail(HS_ERR_INVALID, "bad index kind");
+  if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
+  if (dim == 0) return fail(HS_ERR_INVALID, "dim must be > 0");
+  if (n && enterpoint >= n) return fail(HS_ERR_INVALID, "enter point out of range");
+  if (hs_device_count() <= device) return fail(HS_ERR_DEVICE, "no HIP device (this library has no CPU search path)");
+  PackedIndex p;
+  try {
+    p.kind = kind; p.metric = (Metric)metric; p.n = n; p.dim = dim;
+    p.maxlevel = maxlevel; p.threshold_level = kind == HS_KIND_SLIM ? threshold_level : 0; p.enterpoint = enterpoint;
+    p.vec.assign(vectors, vectors + n * dim);
+    p.labels.resize(n);
+    p.deleted.assign(n, 0);
+    size_t nd = 0;
+    for (size_t i = 0; i < n; i++) {
+      p.labels[i] = labels ? labels[i] : (uint64_t)i;
+      if (deleted) { p.deleted[i] = deleted[i] ? 1 : 0; nd += p.deleted[i]; }
+    }
+    p.has_deleted = nd > 0;
+    p.row_ptr0.assign(n + 1, 0);
+    p.up_base.assign(n, PackedIndex::NONE);
+    size_t t = 0;
+    std::vector<size_t> first(n);
+    for (size_t i = 0; i < n; i++) {   // level-0 lists first (CSR rows), then the upper levels appended to cols
+      if (levels[i] < 0 || levels[i] > maxlevel) return fail(HS_ERR_INVALID, "level out of range");
+      first[i] = t;
+      const uint64_t s0 = list_ptr[t], e0 = list_ptr[t + 1];
+      if (e0 < s0) return fail(HS_ERR_INVALID, "list_ptr not monotone");
+      for (uint64_t j = s0; j < e0; j++) {
+        if (list_ids[j] >= n) return fail(HS_ERR_INVALID, "neighbour id out of range");
+        p.cols.push_back(list_ids[j]);
+      }
+      p.max_deg0 = std::max<size_t>(p.max_deg0, e0 - s0);
+      p.row_ptr0[i + 1] = (uint32_t)p.cols.size();
+      t += (size_t)levels[i] + 1;
+    }
+    for (size_t i = 0; i < n; i++) {
+      if (levels[i] <= 0) continue;
+      p.up_base[i] = (uint32_t)p.up_ptr.size();
+      for (int l = 1; l <= levels[i]; l++) {
+        p.up_ptr.push_back((uint32_t)p.cols.size());
+        const uint64_t s0 = list_ptr[first[i] + l], e0 = list_ptr[first[i] + l + 1];
+        if (e0 < s0) return fail(HS_ERR_INVALID, "list_ptr not monotone");
+        for (uint64_t j = s0; j < e0; j++) {
+          if (list_ids[j] >= n) return fail(HS_ERR_INVALID, "neighbour id out of range");
+          p.cols.push_back(list_ids[j]);
+        }
+      }
+      p.up_ptr.push_back((uint32_t)p.cols.size());
+    }
+    if (p.cols.size() >= PackedIndex::NONE) return fail(HS_ERR_INVALID, "adjacency too large for 32-bit CSR offsets");
+    p.index_size = 16 * n + 4 * p.cols.size();
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  }
+  hs_index *ix = new hs_index();
+  ix->device = device;
+  hs_status s = upload(ix, p);
+  if (s != HS_OK) { delete ix; return s; }
+  *out = ix;
+  return HS_OK;
+}
+
 hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size_t max_elements, int device,
                         hs_index **out) {
   if (!path || !out) return fail(HS_ERR_INVALID, "null argument");

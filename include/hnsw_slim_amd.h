@@ -75,6 +75,14 @@ hs_status hs_index_load(const char *path, int kind, int metric, size_t dim, size
  * (hnsw_slim_server.cc:59-81) or keep it in a buffer; nothing is written to disk.  The bytes are not retained. */
 hs_status hs_index_load_mem(const void *bytes, size_t len, int kind, int metric, size_t dim, size_t max_elements,
                             int device, hs_index **out);
+/* Upload an index the host has already parsed (no file involved): what a caller that holds the reference's public members
+ * (hnswalg_slim.h:30 onwards, all public) or its own graph hands over.  Node i owns levels[i] + 1 consecutive neighbour lists,
+ * level 0 first; list t = list_ids[list_ptr[t] .. list_ptr[t+1]).  labels NULL = row index, deleted NULL = none marked.
+ * kind: HS_KIND_HNSW or HS_KIND_SLIM (selects the searchKnn overload semantics); threshold_level applies to Slim. */
+hs_status hs_index_from_host_arrays(int kind, int metric, size_t n, size_t dim, const float *vectors, const uint64_t *labels,
+                                    const uint8_t *deleted, const int32_t *levels, const uint64_t *list_ptr,
+                                    const uint32_t *list_ids, uint32_t enterpoint, int32_t maxlevel, int32_t threshold_level,
+                                    int device, hs_index **out);
 /* patchFromStream(std::istream&, bool to_add): hnswalg_slim.h:2292-2340, wire format of genPatch :1427-1476 as the reference's
  * server frames it (hnsw_slim_server_patch.cc:280-290, after its `finished` word): u64 cur_element_count, u64 changed_old_cnt,
  * u64 changed_new_cnt, then per changed node  u32 id | 8 B {level, total_neighbor} (old node) or 16 B {level, total, label}

@@ -190,3 +190,29 @@ np.savez(sys.argv[3], **out)
     for key in res["fast"].files:
         assert np.array_equal(res["fast"][key], res["group"][key]), key
         assert np.array_equal(res["fast"][key], res["lean"][key]), key
+
+
+def test_index_from_host_arrays_equals_index_from_file(hs, slim_file):
+    """hs_index_from_host_arrays: the graph handed over as plain arrays (parsed here by the independent Python reader) gives the
+    same index as loading the file -- Slim and vanilla kinds, labels, counters."""
+    from hsutil import load_chal_encode
+    ce = load_chal_encode()
+    g = np.load(os.path.join(GOLDEN, "l2_cont_d32.npz"))
+    s = ce.parse_slim(open(slim_file, "rb").read(), 32)
+    a = hs.Index(slim_file, hs.HS_KIND_SLIM, 32)
+    b = hs.Index.from_arrays(hs.HS_KIND_SLIM, hs.HS_METRIC_L2, s["rows"], s["level"], s["lists"], s["enterpoint"], s["maxlevel"], labels=s["labels"])
+    v = ce.parse_vanilla(open(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), "rb").read())
+    c = hs.Index(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), hs.HS_KIND_HNSW, 32)
+    d = hs.Index.from_arrays(hs.HS_KIND_HNSW, hs.HS_METRIC_L2, v["rows"], [len(x) - 1 for x in v["lists"]], v["lists"], v["enterpoint"],
+                             v["maxlevel"], labels=v["labels"])
+    for ef in (10, 48):
+        for x in (a, b, c, d):
+            x.set_ef(ef)
+        for exact in (True, False):
+            a.set_exact_order(exact); b.set_exact_order(exact)
+            ra, rb = a.search_ids(g["queries"], 10, want_dists=True, want_stats=True), b.search_ids(g["queries"], 10, want_dists=True, want_stats=True)
+            assert np.array_equal(ra["labels"], rb["labels"]) and ra["dists"].tobytes() == rb["dists"].tobytes() and np.array_equal(ra["stats"], rb["stats"])
+        rc, rd = c.search_pq(g["queries"], 10, want_stats=True), d.search_pq(g["queries"], 10, want_stats=True)
+        assert np.array_equal(rc["labels"], rd["labels"]) and rc["dists"].tobytes() == rd["dists"].tobytes() and np.array_equal(rc["stats"], rd["stats"])
+    with pytest.raises(hs.HsError):
+        hs.Index.from_arrays(hs.HS_KIND_SLIM, hs.HS_METRIC_L2, s["rows"], s["level"], s["lists"], 10 ** 9, s["maxlevel"])
