@@ -327,7 +327,7 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
         if (cur_b == kNone) continue;
         uint2 pr = make_uint2(kNone, kNone);
         if ((uint32_t)lane < ix.up_stride) pr = ix.uptile[(size_t)(cur_b + lvl - 1) * ix.up_stride + lane];
-        const uint32_t m = __popcll(__ballot(pr.x != kNone));   // ids are a prefix of the tile
+        const uint32_t m = __popcll(hs_ballot(pr.x != kNone));   // ids are a prefix of the tile
         if (m == 0) continue;
         wave_sync();
         if ((uint32_t)lane < m) nid[lane] = pr.x;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
         c.n_dist += m;
         const float mine = (uint32_t)lane < m ? nd[lane] : FLT_MAX;
         const float d = wave_min_f32(mine);
-        const uint32_t l = (uint32_t)__ffsll((long long)__ballot((uint32_t)lane < m && mine == d)) - 1;
+        const uint32_t l = (uint32_t)__ffsll((long long)hs_ballot((uint32_t)lane < m && mine == d)) - 1;
         if (l < m && d < curdist) {  // hnswalg_slim.h:2071-2075
           curdist = d;
           cur = __builtin_amdgcn_readlane(pr.x, l);
@@ -362,7 +362,7 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
         // first index attaining the minimum == what the sequential `if (d < curdist)` scan ends on
         const float mine = (uint32_t)lane < m ? nd[lane] : FLT_MAX;
         const float d = wave_min_f32(mine);
-        const uint32_t l = (uint32_t)__ffsll((long long)__ballot((uint32_t)lane < m && mine == d)) - 1;
+        const uint32_t l = (uint32_t)__ffsll((long long)hs_ballot((uint32_t)lane < m && mine == d)) - 1;
         if (l < m && d < curdist) {  // hnswalg_slim.h:2071-2075
           curdist = d;
           cur = uni(nid[l]);
@@ -436,7 +436,7 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
 #endif
       HS_LAP(c, 1);
       if ((uint32_t)lane < m) isnew = vis_insert(vis, id);  // :392-393
-      const unsigned long long nm = __ballot(isnew);
+      const unsigned long long nm = hs_ballot(isnew);
       const uint32_t cnt = __popcll(nm);
       c.n_nbr += m;
       if (cnt == 0) continue;
@@ -603,7 +603,7 @@ __device__ __forceinline__ void top_insert(float (&tk)[S], uint32_t (&ti)[S], ui
                                            uint32_t id, int lane) {
   uint32_t pos = 0;  // entries with key <= d stay in front (which equal-key entry is dropped is not defined here)
 #pragma unroll
-  for (int s = 0; s < S; s++) pos += __popcll(__ballot((uint32_t)(lane + 64 * s) < size && tk[s] <= d));
+  for (int s = 0; s < S; s++) pos += __popcll(hs_ballot((uint32_t)(lane + 64 * s) < size && tk[s] <= d));
   uint32_t carry_k = 0, carry_i = 0;
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -645,7 +645,29 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   uint32_t cur;
   float curdist;
   Visited vis;
-  descend<METRIC, D16>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
+  if (a.phase == 2) {
+    // the descent ran in an earlier launch (phase 1): take the level-0 entry from there
+    for (uint32_t i = lane; i < ix.dim; i += 64) qv[i] = a.queries[(size_t)qi * ix.dim + i];
+    vis_init(vis, a, qi, hash, lane);
+    const uint4 e = a.entry[qi];
+    cur = uni(e.x);
+    curdist = unif(__uint_as_float(e.y));
+    c.n_dist = uni(e.z);
+    c.n_hops = uni(e.w);
+    c.n_nbr = c.n_dist - 1;   // the descent evaluates every neighbour it reads, plus the enter point
+    if (a.mark_ep) {  // hnswalg_slim.h:1919
+      wave_sync();
+      if (lane == 0) vis_insert(vis, ix.enterpoint);
+      vis.n1++;
+    }
+    wave_sync();
+  } else {
+    descend<METRIC, D16>(ix, a, qi, qv, vis, hash, nid, nd, c, cur, curdist, lane);
+    if (a.phase == 1) {
+      if (lane == 0) a.entry[qi] = make_uint4(cur, __float_as_uint(curdist), c.n_dist, c.n_hops);
+      return 0;
+    }
+  }
   HS_LAP(c, 5);
 
   constexpr bool bare = BARE;   // no delete marks / filter anywhere in the index (own instantiation, see WB)
@@ -710,13 +732,13 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     }
     HS_LAP(c, 0);
     const bool valid = id != kNone;
-    const uint32_t m = __popcll(__ballot(valid));
+    const uint32_t m = __popcll(hs_ballot(valid));
     HS_LAP(c, 1);
     if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
     if (__builtin_expect(cand_size + m > cand_total, 0)) { rc = 2; break; }
     bool isnew = false;
     if (valid) isnew = vis_insert(vis, id);  // :392-393
-    const unsigned long long nm = __ballot(isnew);
+    const unsigned long long nm = hs_ballot(isnew);
     const uint32_t cnt = __popcll(nm);
     c.n_nbr += m;
     wave_sync();
@@ -752,7 +774,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
       // accepted keys strictly below it, an accepted one lands at #{T <= d} + #{accepted before it in (d, j) order}.
       // Same set, same lowerBound sequence as far as any decision can see, a third of the vector instructions.
       const bool cand_ok = (uint32_t)lane < cnt && (top_size < ef || lb > my_d);
-      const unsigned long long pm = __ballot(cand_ok);
+      const unsigned long long pm = hs_ballot(cand_ok);
       if (pm) {
         uint32_t A = 0, B = 0;
         for (unsigned long long m = pm; m; m &= m - 1) {
@@ -760,12 +782,12 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
           const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
           uint32_t a = 0;
 #pragma unroll
-          for (int s = 0; s < S; s++) a += __popcll(__ballot((uint32_t)(lane + 64 * s) < top_size && tk[s] <= dj));
-          if (lane == j) A = a;
+          for (int s = 0; s < S; s++) a += __popcll(hs_ballot((uint32_t)(lane + 64 * s) < top_size && tk[s] <= dj));
+          A = write_lane(A, a, j);
           B += (cand_ok && lane > j && dj <= my_d) ? 1u : 0u;
         }
         const bool acc = cand_ok && (A + B < ef);
-        const unsigned long long am = __ballot(acc);
+        const unsigned long long am = hs_ballot(acc);
         const uint32_t n_acc = __popcll(am);
         uint32_t Bp = 0, shift[S];
 #pragma unroll
@@ -811,7 +833,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         pending |= am;
         if (am) {
           // the earliest accepted entry with the smallest distance is the one no accepted entry precedes in (d, j) order
-          const int bl = __ffsll((long long)__ballot(acc && Bp == 0)) - 1;
+          const int bl = __ffsll((long long)hs_ballot(acc && Bp == 0)) - 1;
           best_d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), bl));
           best_id = __builtin_amdgcn_readlane(my_id, bl);
           have_best = true;
@@ -825,7 +847,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     } else {
     // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
     // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
-    unsigned long long todo = __ballot((uint32_t)lane < cnt && (top_size < ef || lb > my_d));
+    unsigned long long todo = hs_ballot((uint32_t)lane < cnt && (top_size < ef || lb > my_d));
     while (todo) {
       const int j = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
@@ -952,7 +974,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
     unsigned long long m = 1ull;
     if (scan) {
       const uint32_t q = base + threadIdx.x;
-      m = __ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
+      m = hs_ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
     }
     while (m) {
       const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
@@ -973,7 +995,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
 template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D16 > 16 ? 3 : HS_FAST_WAVES))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+  for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x) {
+    const uint32_t qi = a.phase == 2 ? a.order[it] : it;
     if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;  // pass 0 takes every query
     if (ix.n == 0) {
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
@@ -995,6 +1018,65 @@ static hipError_t launch(K kern, const DevIndex &ix, const SearchArgs &a, size_t
   hipLaunchKernelGGL(kern, dim3(std::max(1u, std::min(a.grid, a.nq))), dim3(64), lds, stream, ix, a);
   return hipGetLastError();
 }
+
+#if HS_TU_HAS_L2
+// ---- query order for a two-launch fast pass --------------------------------------------------------------------------
+// One workgroup: min / max of the entry distances, a 4096-bin histogram over that range (farthest first), its prefix
+// sums, then each query takes the next free position of its bin.  Order inside a bin is whatever the atomics give: the
+// order only decides when a query STARTS, never what it returns.
+constexpr uint32_t kOrderBins = 4096, kOrderThreads = 1024;
+__global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry, uint32_t *order, uint32_t nq) {
+  __shared__ uint32_t bins[kOrderBins];
+  __shared__ float red_lo[kOrderThreads / 64], red_hi[kOrderThreads / 64];
+  __shared__ uint32_t wave_tot[kOrderThreads / 64];
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (uint32_t i = t; i < nq; i += kOrderThreads) {
+    const float d = __uint_as_float(entry[i].y);
+    if (d == d && fabsf(d) <= FLT_MAX) { lo = fminf(lo, d); hi = fmaxf(hi, d); }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+  if (lane == 0) { red_lo[wv] = lo; red_hi[wv] = hi; }
+  for (uint32_t b = t; b < kOrderBins; b += kOrderThreads) bins[b] = 0;
+  __syncthreads();
+  lo = red_lo[0]; hi = red_hi[0];
+  for (uint32_t w = 1; w < kOrderThreads / 64; w++) { lo = fminf(lo, red_lo[w]); hi = fmaxf(hi, red_hi[w]); }
+  const float scale = hi > lo ? (float)(kOrderBins - 1) / (hi - lo) : 0.f;
+  auto bin_of = [&](float d) -> uint32_t {
+    if (!(d == d)) return 0;                       // NaN: with the farthest
+    const float x = (hi - fminf(fmaxf(d, lo), hi)) * scale;
+    return min((uint32_t)x, kOrderBins - 1);
+  };
+  for (uint32_t i = t; i < nq; i += kOrderThreads) atomicAdd(&bins[bin_of(__uint_as_float(entry[i].y))], 1u);
+  __syncthreads();
+  // exclusive prefix sums of the bins: four consecutive bins per thread, wave scan, then the wave totals
+  uint32_t v[4], sum = 0;
+  for (int j = 0; j < 4; j++) { v[j] = bins[4 * t + j]; sum += v[j]; }
+  uint32_t incl = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off);
+    if (lane >= (uint32_t)off) incl += up;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wv; w++) base += wave_tot[w];
+  uint32_t run = base + incl - sum;
+  __syncthreads();
+  for (int j = 0; j < 4; j++) { bins[4 * t + j] = run; run += v[j]; }
+  __syncthreads();
+  for (uint32_t i = t; i < nq; i += kOrderThreads) order[atomicAdd(&bins[bin_of(__uint_as_float(entry[i].y))], 1u)] = i;
+}
+hipError_t launch_order(const uint4 *entry, uint32_t *order, uint32_t nq, hipStream_t stream) {
+  static_assert(kOrderBins == 4 * kOrderThreads, "four bins per thread in the prefix step");
+  if (nq == 0) return hipSuccess;
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, entry, order, nq);
+  return hipGetLastError();
+}
+#endif
 
 hipError_t launch_strict_l2(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream);
 hipError_t launch_strict_ip(const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream);

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(64 * kWaves) bf_scan_kernel(const float *base,
       if (q0 + t >= nq) continue;
       const uint32_t sz = msz[t];
       const float thr = sz < k ? FLT_MAX : mine[(size_t)t * k + k - 1].d;
-      bf_offer<2>(__ballot(act && owner && d <= thr), d, rb, labels, mine + (size_t)t * k, msz + t, k, lane);   // bruteforce.h:120 `dist <= lastdist`
+      bf_offer<2>(hs_ballot(act && owner && d <= thr), d, rb, labels, mine + (size_t)t * k, msz + t, k, lane);   // bruteforce.h:120 `dist <= lastdist`
     }
   }
   wave_sync();
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * kWaves) bf_scan_general_kernel(const floa
       const float d = METRIC == METRIC_L2 ? l2_general(q + (size_t)t * dim, x, dim) : ip_general(q + (size_t)t * dim, x, dim);
       const uint32_t sz = msz[t];
       const float thr = sz < k ? FLT_MAX : mine[(size_t)t * k + k - 1].d;
-      bf_offer<0>(__ballot(act && d <= thr), d, rb, labels, mine + (size_t)t * k, msz + t, k, lane);
+      bf_offer<0>(hs_ballot(act && d <= thr), d, rb, labels, mine + (size_t)t * k, msz + t, k, lane);
     }
   }
   wave_sync();
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64) bf_merge_kernel(const BfEntry *partial, ui
       }
     }
     const float md = wave_min_f32(bj >= 0 ? bd : FLT_MAX);
-    unsigned long long m = __ballot(bj >= 0 && bd == md);
+    unsigned long long m = hs_ballot(bj >= 0 && bd == md);
     if (!m) break;
     int win = __ffsll((long long)m) - 1;
     uint64_t wl = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bl >> 32), win) << 32) | __builtin_amdgcn_readlane((uint32_t)bl, win);

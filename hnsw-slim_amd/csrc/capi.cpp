@@ -92,6 +92,7 @@ struct hs_index {
     DevBuf<uint32_t> spill;             // visited-set tier 2, nq x kSpillSlots
     DevBuf<uint32_t> prep;              // SlimQ: per-query preparation records
     DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, tier-2 spills}
+    DevBuf<uint32_t> entry, order;      // two-launch fast pass: level-0 entries (nq x 4 words) and the start order
     size_t last_nq = 0;
     // hs_search_batch_async: device staging of the queries and outputs of the call in flight on this stream
     DevBuf<float> aq, adist;
@@ -634,6 +635,8 @@ hs_status hs_index_info(const hs_index *ix, hs_info *out) {
 // One launch group serves at most kMaxLaunchQueries queries: the per-query scratch in global memory (96 KiB each) is
 // sized for that many, larger batches run as consecutive groups on the same stream (counters accumulate).
 static constexpr size_t kMaxLaunchQueries = 32768;
+// from this many queries per launch the fast pass runs as descent / order / level-0 search (see search_dev_group)
+static constexpr size_t kOrderMinQueries = 6144;
 
 static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, size_t k, int mode, uint32_t *l32,
                                   uint64_t *l64, float *dd, uint32_t *cnt, uint32_t *stats, Pair *raw, uint32_t *rawsz,
@@ -681,11 +684,25 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
                     lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.l_hash_slots) <= kLdsPerCU;
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
+  static const int order_env = getenv("HS_ORDER") ? atoi(getenv("HS_ORDER")) : -1;   // diagnostic: 0 = never, 1 = always
+  const bool ordered = fast && !group && (order_env < 0 ? nq >= kOrderMinQueries : order_env != 0);
   if (lean) {
     // pass 0: the lean kernel; a query that exhausts even its tier-2 regions is left ST_OVERFLOW for the passes below
     a.cand_cap = sh.l_cand_cap; a.hash_slots = sh.l_hash_slots; a.hash_fill_shift = 3;
     a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
-    HIP_TRY(launch_lean(ix->dev, a, stream));
+    if (ordered) {   // descent / order / level-0 search, as for the fast kernel below
+      HIP_TRY(w->entry.ensure(nq * 4));
+      HIP_TRY(w->order.ensure(nq));
+      a.entry = reinterpret_cast<uint4 *>(w->entry.p); a.order = w->order.p;
+      a.phase = 1;
+      HIP_TRY(launch_lean(ix->dev, a, stream));
+      HIP_TRY(launch_order(a.entry, w->order.p, (uint32_t)nq, stream));
+      a.phase = 2;
+      HIP_TRY(launch_lean(ix->dev, a, stream));
+      a.phase = 0;
+    } else {
+      HIP_TRY(launch_lean(ix->dev, a, stream));
+    }
     a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.hash_fill_shift = 0;
   } else if (group) {
     // pass 0: the group kernel (four queries per wavefront, persistent grid) answers every query; one whose scratch runs
@@ -704,19 +721,38 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     if (fast) a.cand_cap = sh.cand_cap_fast;
     // pass 0: every query, one wavefront each
     a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
-    HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
+    // A launch much larger than what the GPU holds at once (4096 wavefronts of this kernel) ends on the queries that
+    // started last; if those are long ones the whole chip waits for them.  The distance of the level-0 entry predicts
+    // the number of expansions (rank correlation 0.5 on the bench data), so the descent runs as a launch of its own,
+    // the queries are ordered by that distance, farthest first, and the level-0 search takes them in that order.
+    if (ordered) {
+      HIP_TRY(w->entry.ensure(nq * 4));
+      HIP_TRY(w->order.ensure(nq));
+      a.entry = reinterpret_cast<uint4 *>(w->entry.p); a.order = w->order.p;
+      a.phase = 1;
+      HIP_TRY(launch_fast(ix->dev, a, stream));
+      HIP_TRY(launch_order(a.entry, w->order.p, (uint32_t)nq, stream));
+      a.phase = 2;
+      HIP_TRY(launch_fast(ix->dev, a, stream));
+      a.phase = 0;
+    } else {
+      HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
+    }
   }
+  // Both re-run passes are normally empty (a launch that scans the statuses and exits), so they share one launch whenever
+  // the whole-CU pass exists: a batch is then two kernel launches, not three.
+  const bool big_pass = sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots;
   // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
-  if (fast || group || lean) {
+  if ((fast || group || lean) && !big_pass) {
     a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
     a.counters = w->counters.p + 4; a.pass_id = 1;
     HIP_TRY(launch_strict(ix->dev, a, stream));
   }
-  // pass 2: queries that outgrew their scratch -> strict kernel with a whole CU's LDS each
-  if (sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots) {
+  // pass 2: queries that outgrew their scratch (and, see above, pass 1's) -> strict kernel with a whole CU's LDS each
+  if (big_pass) {
     // few workgroups: each needs a whole CU's LDS, i.e. a CU drained of every other wave before it can start -- with
     // several batches in flight a wide grid of them stalls the stream even when (as usual) no query is flagged
-    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 16);
+    a.select_mask = (1u << ST_OVERFLOW) | ((fast || group || lean) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, 16);
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
     a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t cv_prune(const float *vec, uint32_t dim, con
       wave_sync();
       bool bad = false;
       for (uint32_t i = lane; i < kc; i += 64) bad = bad || kd[i] < cd;
-      good = __ballot(bad) == 0;
+      good = hs_ballot(bad) == 0;
     }
     if (good) {
       if (lane == 0) kept[kc] = cid;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void cv_sort_by_dist(const uint32_t *nid, const float
       rank += (di < my_d || (di == my_d && i < (uint32_t)lane)) ? 1u : 0u;
       tie = tie || (di == my_d && i != (uint32_t)lane);
     }
-    const bool anytie = __ballot(act && tie) != 0;
+    const bool anytie = hs_ballot(act && tie) != 0;
     if (sz <= 16 || !anytie) {
       if (act) arr[rank] = Pair{my_d, my_id};
       wave_sync();
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64) cv_union_kernel(const float *vec, uint32_t
       const uint32_t i = base + lane;
       const uint32_t x = i < total ? ids[i] : 0u;
       const bool first = i < total && (i == 0 || ids[i - 1] != x);
-      const unsigned long long fm = __ballot(first);
+      const unsigned long long fm = hs_ballot(first);
       wave_sync();
       if (first) ids[m + __popcll(fm & ((1ull << lane) - 1ull))] = x;   // m + prefix <= i: never overwrites an unread entry of a later chunk
       m += __popcll(fm);

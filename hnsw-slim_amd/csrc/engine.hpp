@@ -54,6 +54,12 @@ struct SearchArgs {
   uint32_t pass_id;
   uint32_t *queue;       // group kernel: device-wide query counter (zeroed per launch group)
   uint32_t hash_fill_shift;   // visited-set tier 1 is frozen at 1 - 2^-shift of its slots (0 = the default 2: 75 %)
+  // Fast kernel in two launches (see launch_order): phase 1 stops after the upper-level descent and leaves
+  // {level-0 entry node, its distance, n_dist, n_hops} in entry[qi]; phase 2 takes its queries in the order order[] gives
+  // and starts each from its entry.  phase 0: one launch does both, in index order.
+  uint32_t phase;
+  uint4 *entry;
+  const uint32_t *order;
 };
 
 // Bytes of dynamic LDS one query (one wavefront) needs.
@@ -66,6 +72,9 @@ bool fast_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 // output order.  Fast kernel: same traversal and candidate mechanics, result set kept as a sorted
 // register array; queries whose answer could depend on the result heap's layout are flagged ST_HAZARD.
 hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+// order[] = the queries sorted by decreasing entry[].y (distance of the level-0 entry), bucket-exact: the queries likely
+// to take the most expansions start first, so that a launch does not end on a few late-started long ones.
+hipError_t launch_order(const uint4 *entry, uint32_t *order, uint32_t nq, hipStream_t stream);
 // Lean kernel (lean_search.hip): the fast kernel's algorithm with a keys-only result set (no ids, no LDS staging of the merge).
 bool lean_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);

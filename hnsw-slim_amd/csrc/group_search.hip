@@ -188,7 +188,7 @@ __device__ __forceinline__ void g_cand_push(const GHeap &heap, uint32_t n /*size
   const bool has = act && anc != 0;
   uint2 p = make_uint2(0, 0);
   if (has) p = gh_get<T2>(heap, anc);
-  const uint32_t rises = gbits(__ballot(has && __uint_as_float(p.x) > d), lane);
+  const uint32_t rises = gbits(hs_ballot(has && __uint_as_float(p.x) > d), lane);
   const uint32_t r = __ffs(~rises) - 1;   // consecutive ancestors passed (< 16: the heap holds fewer than 65536 entries)
   if (act) {
     if ((uint32_t)l < r) gh_set<T2>(heap, n >> l, p);
@@ -370,12 +370,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
 
   while (true) {
     // ================= refill: idle groups pull the next query ========================================================
-    if (__ballot(st == G_IDLE) && !queue_empty) {
+    if (hs_ballot(st == G_IDLE) && !queue_empty) {
       uint32_t got = 0;
       if (st == G_IDLE && l == 0) got = atomicAdd(a.queue, 1u);
       got = row_bcast(got, 0, lane);
       const bool take = st == G_IDLE && got < a.nq;
-      if (__ballot(st == G_IDLE && got >= a.nq)) queue_empty = true;
+      if (hs_ballot(st == G_IDLE && got >= a.nq)) queue_empty = true;
       if (take) {
         qi = got;
         const float *qsrc = a.queries + (size_t)qi * dim;
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         st = G_INIT;
       }
     }
-    if (!__ballot(st != G_IDLE)) break;
+    if (!hs_ballot(st != G_IDLE)) break;
     wave_sync();
     GP_LAP(0);
     GP_CNT(10, 1);
@@ -411,19 +411,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
     //                   the tile of the node being expanded is in flight =================================================
     {
       const bool beam = st == G_BEAM;
-      while (__ballot(beam && pending != 0)) {
+      while (hs_ballot(beam && pending != 0)) {
         const bool act = beam && pending != 0;
         const uint32_t j = act ? (uint32_t)__ffs(pending) - 1u : 0u;
         float d = 0.f;
         uint32_t id = 0;
         if (act) { d = nd[j]; id = nid[j]; pending &= pending - 1; cand_size++; }
-        if (__builtin_expect(__ballot(act && cand_size >= cand.L) == 0, 1)) g_cand_push<false>(cand, cand_size, d, id, act, lane);
+        if (__builtin_expect(hs_ballot(act && cand_size >= cand.L) == 0, 1)) g_cand_push<false>(cand, cand_size, d, id, act, lane);
         else g_cand_push<true>(cand, cand_size, d, id, act, lane);
         wave_sync();
         GP_CNT(11, 1);
       }
       GP_LAP(1);
-      if (__builtin_expect(__ballot(beam && cand_size >= cand.L) == 0, 1)) {
+      if (__builtin_expect(hs_ballot(beam && cand_size >= cand.L) == 0, 1)) {
         if (beam && l == 0) g_cand_pop<false>(cand, cand_size);
       } else {
         if (beam && l == 0) g_cand_pop<true>(cand, cand_size);
@@ -450,13 +450,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         const bool v0 = ut0.x != kNoneG, v1 = ut1.x != kNoneG;
         if (v0) { nid[l] = ut0.x; nub[l] = ut0.y; }
         if (v1) { nid[16 + l] = ut1.x; nub[16 + l] = ut1.y; }
-        cnt = __popc(gbits(__ballot(v0), lane)) + __popc(gbits(__ballot(v1), lane));
+        cnt = __popc(gbits(hs_ballot(v0), lane)) + __popc(gbits(hs_ballot(v1), lane));
         n_nbr += cnt;
       }
     } else if (st == G_BEAM) {
       // the node's whole level-0 list is one aligned tile (hnswalg_slim.h:363-369); test-and-mark every id (:392-393)
       const bool v0 = t0a != kNoneG, v1 = t0b != kNoneG;
-      const uint32_t m = __popc(gbits(__ballot(v0), lane)) + __popc(gbits(__ballot(v1), lane));
+      const uint32_t m = __popc(gbits(hs_ballot(v0), lane)) + __popc(gbits(hs_ballot(v1), lane));
       n_nbr += m;
       if (__builtin_expect(!spilled && n_vis + m > vis_limit, 0)) {
         // tier 1 is full: clear the query's tier-2 table and continue there
@@ -468,14 +468,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
       fail = (spilled && n_vis2 + m > vis_limit2) ? 1u : ((cand_size + m > cand_total) ? 2u : 0u);
       if (!fail) {
         bool new0 = false, new1 = false;
-        if (__builtin_expect(__ballot(spilled) == 0, 1)) {
+        if (__builtin_expect(hs_ballot(spilled) == 0, 1)) {
           if (v0) new0 = g_vis_insert(hash, nbuckets, t0a);
           if (v1) new1 = g_vis_insert(hash, nbuckets, t0b);
         } else {
           if (v0) new0 = g_vis_insert2(hash, nbuckets, spilled, vis2, nbuckets2, t0a);
           if (v1) new1 = g_vis_insert2(hash, nbuckets, spilled, vis2, nbuckets2, t0b);
         }
-        const uint32_t b0 = gbits(__ballot(new0), lane), b1 = gbits(__ballot(new1), lane);
+        const uint32_t b0 = gbits(hs_ballot(new0), lane), b1 = gbits(hs_ballot(new1), lane);
         const uint32_t below = (1u << l) - 1u;
         const uint32_t pre = __popc(b0 & below) + __popc(b1 & below);   // unvisited ids before adjacency position 2l (resp. l)
         if (new0) nid[pre] = t0a;
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         else n_vis += cnt;
       }
     }
-    if (__builtin_expect(__ballot(fail != 0) != 0, 0)) {
+    if (__builtin_expect(hs_ballot(fail != 0) != 0, 0)) {
       if (fail) {   // scratch exhausted: the query is re-run by the one-query-per-wave kernels (tier 2 / whole-CU passes)
         if (l == 0) {
           a.status[qi] = ST_OVERFLOW;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         const float d0 = (uint32_t)l < cnt ? nd[l] : kInf, d1 = (uint32_t)(16 + l) < cnt ? nd[16 + l] : kInf;
         const float mn = row_min_f32(fminf(d0, d1));
         if (mn < curdist) {
-          const uint32_t e0 = gbits(__ballot(d0 == mn), lane), e1 = gbits(__ballot(d1 == mn), lane);
+          const uint32_t e0 = gbits(hs_ballot(d0 == mn), lane), e1 = gbits(hs_ballot(d1 == mn), lane);
           const uint32_t j = e0 ? (uint32_t)__ffs(e0) - 1u : 16u + (uint32_t)__ffs(e1) - 1u;
           curdist = mn;
           cur = nid[j];
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
     } else if (st == G_BEAM && cnt) {
       // candidates of this tile that can pass `top_size < ef || lowerBound > d` (:403-404); lowerBound only falls
       const float d0 = (uint32_t)l < cnt ? nd[l] : kInf, d1 = (uint32_t)(16 + l) < cnt ? nd[16 + l] : kInf;
-      todo = gbits(__ballot(d0 < lb_eff), lane) | (gbits(__ballot(d1 < lb_eff), lane) << 16);
+      todo = gbits(hs_ballot(d0 < lb_eff), lane) | (gbits(hs_ballot(d1 < lb_eff), lane) << 16);
     }
     wave_sync();
 
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
     float best_d = kInf;
     uint32_t best_id = 0;
     GP_LAP(6);
-    while (__ballot(todo != 0)) {
+    while (hs_ballot(todo != 0)) {
       GP_CNT(12, 1);
       const bool act = todo != 0;
       const uint32_t j = act ? (uint32_t)__ffs(todo) - 1u : 0u;
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
       }
       // replace one instance of the set's maximum by d (push_heap + pop_heap of the reference, keys only): the first lane
       // whose column tops out at lb_eff drops that entry and bubbles d into its sorted column
-      const uint32_t hb = gbits(__ballot(ok && tk[0] == lb_eff), lane);
+      const uint32_t hb = gbits(hs_ballot(ok && tk[0] == lb_eff), lane);
       if (ok && (uint32_t)l == (uint32_t)__ffs(hb) - 1u) {
         float c = d;
 #pragma unroll
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
 
     GP_LAP(8);
     // ================= finish: k-selection and output =====================================================================
-    if (__builtin_expect(__ballot(finish) != 0, 0)) {
+    if (__builtin_expect(hs_ballot(finish) != 0, 0)) {
       GP_CNT(14, 1);
       wave_sync();
       const uint32_t top_size = min(n_acc, ef);
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         // columns: move the -inf "beyond ef" slots off the bottom (as +inf on top) so that every lane's minimum is its last slot
         for (int it = 0; it < SP; it++) {
           const bool sh = tk[SP - 1] == -kInf;
-          if (!__ballot(sh)) break;
+          if (!hs_ballot(sh)) break;
           if (sh) {
 #pragma unroll
             for (int s = SP - 1; s > 0; s--) tk[s] = tk[s - 1];
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         }
         for (uint32_t i = 0; i < valid_n; i++) {
           const float mn = row_min_f32(tk[SP - 1]);
-          const uint32_t hb = gbits(__ballot(tk[SP - 1] == mn), lane);
+          const uint32_t hb = gbits(hs_ballot(tk[SP - 1] == mn), lane);
           if ((uint32_t)l == (uint32_t)__ffs(hb) - 1u) {
 #pragma unroll
             for (int s = SP - 1; s > 0; s--) tk[s] = tk[s - 1];
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
           uint2 e = make_uint2(0, 0);
           if (idx < n_acc) e = tlog[idx];
           const bool mt = idx < n_acc && __uint_as_float(e.x) <= kth;
-          const uint32_t mb = gbits(__ballot(mt), lane);
+          const uint32_t mb = gbits(hs_ballot(mt), lane);
           const uint32_t at = nm + __popc(mb & ((1u << l) - 1u));
           if (mt && at < kGroupScratch) { nd[at] = __uint_as_float(e.x); nid[at] = e.y; }
           nm += __popc(mb);
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
           if (a.out_dists) a.out_dists[(size_t)qi * k + l] = kInf;
         }
       }
-      if (__builtin_expect(__ballot(finish && !hazard && replay) != 0, 0)) {
+      if (__builtin_expect(hs_ballot(finish && !hazard && replay) != 0, 0)) {
         // the reference's result heap rebuilt exactly: the logged insertions replayed through libstdc++'s push_heap /
         // pop_heap (hnswalg_slim.h:419-448) and the final nth_element (:2126) or pop_heap loop (:2019-2022), in the
         // (dead by now) visited-set area
@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) gr
         Pair *top = reinterpret_cast<Pair *>(hash);
         uint32_t ts = 0;
         const uint32_t nlog = rp ? n_acc : 0u;
-        for (uint32_t base = 0; __ballot(base < nlog); base += 16) {
+        for (uint32_t base = 0; hs_ballot(base < nlog); base += 16) {
           uint2 e = make_uint2(0, 0);
           if (base + l < nlog) e = tlog[base + l];
           wave_sync();

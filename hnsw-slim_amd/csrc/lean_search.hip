@@ -173,9 +173,24 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
   Visited vis;
   vis_init(vis, a, qi, hash, lane);
   uint32_t cur = ix.enterpoint;
+  float curdist = 0.f;
+  if (a.phase == 2) {
+    // the descent ran in an earlier launch (SearchArgs::phase): its result and its counters come from entry[]
+    if (a.mark_ep) {   // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
+      wave_sync();
+      if (lane == 0) vis_insert(vis, cur);
+      vis.n1++;
+    }
+    const uint4 e = a.entry[qi];
+    cur = uni(e.x);
+    curdist = unif(__uint_as_float(e.y));
+    n_dist = uni(e.z);
+    n_hops = uni(e.w);
+    n_nbr = n_dist - 1;
+  } else {
   if (lane == 0) nid[0] = cur;
   wave_sync();
-  float curdist = unif(wave_dists8<METRIC, D16>(ix.vec, dim, qv, nid, 1, lane, NoHook8()));
+  curdist = unif(wave_dists8<METRIC, D16>(ix.vec, dim, qv, nid, 1, lane, NoHook8()));
   if (a.mark_ep) {   // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
     if (lane == 0) vis_insert(vis, cur);
     vis.n1++;
@@ -189,7 +204,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
       if (cur_b == kNone) continue;
       uint2 pr = make_uint2(kNone, kNone);
       if ((uint32_t)lane < ix.up_stride) pr = ix.uptile[(size_t)(cur_b + lvl - 1) * ix.up_stride + lane];
-      const uint32_t m = __popcll(__ballot(pr.x != kNone));   // ids are a prefix of the tile
+      const uint32_t m = __popcll(hs_ballot(pr.x != kNone));   // ids are a prefix of the tile
       if (m == 0) continue;
       wave_sync();
       if ((uint32_t)lane < m) nid[lane] = pr.x;
@@ -198,7 +213,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
       n_nbr += m;
       n_dist += m;
       const float d = wave_min_f32(mine);
-      const uint32_t l = (uint32_t)__ffsll((long long)__ballot((uint32_t)lane < m && mine == d)) - 1;
+      const uint32_t l = (uint32_t)__ffsll((long long)hs_ballot((uint32_t)lane < m && mine == d)) - 1;
       if (l < m && d < curdist) {   // first index attaining the minimum == where the sequential scan ends (:2071-2075)
         curdist = d;
         cur = __builtin_amdgcn_readlane(pr.x, l);
@@ -206,6 +221,11 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
         changed = true;
       }
     }
+  }
+  if (a.phase == 1) {
+    if (lane == 0) a.entry[qi] = make_uint4(cur, __float_as_uint(curdist), n_dist, n_hops);
+    return 0;
+  }
   }
   if (ix.kind == 0) n_dist++;   // searchBaseLayerST recomputes the entry distance (hnswalg.h:347-351)
 
@@ -260,12 +280,12 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
       wave_sync();
     }
     const bool valid = id != kNone;
-    const uint32_t m = __popcll(__ballot(valid));
+    const uint32_t m = __popcll(hs_ballot(valid));
     if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
     if (__builtin_expect(cand_size + m > cand_total, 0)) { rc = 2; break; }
     bool isnew = false;
     if (valid) isnew = vis_insert(vis, id);   // :392-393
-    const unsigned long long nm = __ballot(isnew);
+    const unsigned long long nm = hs_ballot(isnew);
     const uint32_t cnt = __popcll(nm);
     n_nbr += m;
     wave_sync();
@@ -291,7 +311,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
     my_id = (uint32_t)lane < cnt ? nid[lane] : 0;
     // ---- accept (:403-452), adjacency order.  lowerBound only falls, so a candidate that fails it now never passes later.
     const int my_key = (uint32_t)lane < cnt ? fkey(my_d) : kKeyInf;
-    unsigned long long todo = __ballot(my_key < lb_key);
+    unsigned long long todo = hs_ballot(my_key < lb_key);
     float best_d = FLT_MAX;
     uint32_t best_id = 0;
     bool have_best = false;
@@ -307,7 +327,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
         if (lane == 0 && n_acc < a.log_cap) tlog[n_acc] = make_uint2(__float_as_uint(dj), idj);   // insertion log (:418-423)
         rmax_key = max(rmax_key, kj);
         // replace one instance of the set's maximum by the new key (push_heap + pop_heap of the reference, keys only)
-        const int holder = __ffsll((long long)__ballot(tk[0] == lb_key)) - 1;
+        const int holder = __ffsll((long long)hs_ballot(tk[0] == lb_key)) - 1;
         if (lane == holder) {
           int c = kj;
 #pragma unroll
@@ -342,7 +362,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
   // columns hold +inf (empty), the keys descending, INT_MIN (slots beyond ef): bring every lane's smallest real key to its last slot
   for (int it = 0; it < S; it++) {
     const bool sh = tk[S - 1] == INT_MIN;
-    if (!__ballot(sh)) break;
+    if (!hs_ballot(sh)) break;
     if (sh) {
 #pragma unroll
       for (int s = S - 1; s > 0; s--) tk[s] = tk[s - 1];
@@ -352,7 +372,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
   int kth = INT_MIN;
   for (uint32_t i = 0; i < valid_n; i++) {
     const int mn = wave_min_i32(tk[S - 1]);
-    const int holder = __ffsll((long long)__ballot(tk[S - 1] == mn)) - 1;
+    const int holder = __ffsll((long long)hs_ballot(tk[S - 1] == mn)) - 1;
     if (lane == holder) {
 #pragma unroll
       for (int s = S - 1; s > 0; s--) tk[s] = tk[s - 1];
@@ -368,7 +388,7 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
     uint2 e = make_uint2(0, 0);
     if (idx < n_acc) e = tlog[idx];
     const bool mt = idx < n_acc && fkey(__uint_as_float(e.x)) <= kth;
-    const unsigned long long mb = __ballot(mt);
+    const unsigned long long mb = hs_ballot(mt);
     const uint32_t at = nm + __popcll(mb & ((1ull << lane) - 1ull));
     if (mt && at < 64) { nd[at] = __uint_as_float(e.x); nid[at] = e.y; }
     nm += __popcll(mb);
@@ -457,7 +477,8 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
 template <int METRIC, int S, int D16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_LEAN_WAVES))) lean_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+  for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x) {
+    const uint32_t qi = a.phase == 2 ? a.order[it] : it;
     if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;   // pass 0 takes every query
     const int rc = search_one_lean<METRIC, S, D16>(ix, a, qi, smem);
     if (rc == 3 && threadIdx.x == 0) a.status[qi] = ST_HAZARD;

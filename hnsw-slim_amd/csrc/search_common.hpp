@@ -131,7 +131,7 @@ __device__ __forceinline__ void cand_push_t(const CandHeap &h, uint32_t n /*size
   const bool has = anc != 0 && lane < 31;
   uint2 p = make_uint2(0, 0);
   if (has) p = ch_get<T2>(h, anc);               // element anc-1 lives at slot anc
-  const unsigned long long rises = __ballot(has && __uint_as_float(p.x) > d);
+  const unsigned long long rises = hs_ballot(has && __uint_as_float(p.x) > d);
   const uint32_t r = __ffsll((long long)~rises) - 1;  // number of consecutive ancestors passed
   if ((uint32_t)lane < r) ch_set<T2>(h, n >> lane, p);  // ancestor t moves to the path node below it ((n >> (t-1)) - 1)
   if ((uint32_t)lane == r) ch_set<T2>(h, n >> r, make_uint2(__float_as_uint(d), id));

@@ -98,7 +98,7 @@ template <int S>
 __device__ __forceinline__ void pool_insert(float (&key)[S], uint32_t (&val)[S], PoolState<S> &p, float d, uint32_t id, int lane) {
   uint32_t pos = 0;
 #pragma unroll
-  for (int s = 0; s < S; s++) pos += __popcll(__ballot(key[s] < d));
+  for (int s = 0; s < S; s++) pos += __popcll(hs_ballot(key[s] < d));
   const uint32_t sp = pos >> 6, lp = pos & 63;
   uint32_t carry_k = 0, carry_v = 0;
 #pragma unroll
@@ -139,7 +139,7 @@ __device__ __forceinline__ uint32_t pool_pop(uint32_t (&val)[S], PoolState<S> &p
       id = __builtin_amdgcn_readlane(val[s], lc);
       if ((uint32_t)lane == lc) val[s] |= kChecked;
     }
-    unsigned long long m = __ballot((int)val[s] >= 0);
+    unsigned long long m = hs_ballot((int)val[s] >= 0);
     const int lim = (int)p.cap - 64 * s;               // ranks of this slot below the capacity
     if (lim <= 0) m = 0ull;
     else if (lim < 64) m &= (1ull << lim) - 1;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(64) slimq_prep_kernel(DevSlimQ sq, uint32_t di
       u[b * 64 + lane] = (float)c + (-7.5f);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const unsigned long long m = __ballot((c >> j) & 1);
+        const unsigned long long m = hs_ballot((c >> j) & 1);
         if (lane == 0) planes_lds[b * 4 + j] = __brevll(m);   // dimension i -> bit 63 - i%64
       }
     }
@@ -452,12 +452,12 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
           const uint4 h = *reinterpret_cast<const uint4 *>(r);
           const uint32_t nb_b = r[sq.rec_words];
           const bool act = slot < sq.up_stride && h.w != kNoneQ;
-          const unsigned long long am = __ballot(act);
+          const unsigned long long am = hs_ballot(act);
           if (!am) break;
           const float mine = act ? est_rec<NBLK>(sq, planes, gadd, delta, vl, k1, r, h) : FLT_MAX;
           n_est += __popcll(am);
           const float d = wave_min_f32(mine);
-          const unsigned long long eq = __ballot(act && mine == d);
+          const unsigned long long eq = hs_ballot(act && mine == d);
           if (eq && d < curd) {
             const int l = __ffsll((long long)eq) - 1;
             curd = d;
@@ -478,7 +478,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         const float mine = act ? est_one<NBLK>(sq, planes, gadd, delta, vl, k1, c) : FLT_MAX;
         n_est += m;
         const float d = wave_min_f32(mine);
-        const unsigned long long eq = __ballot(act && mine == d);
+        const unsigned long long eq = hs_ballot(act && mine == d);
         if (eq && d < curd) {  // the sequential `if (d < curdist)` scan ends on the first index attaining the minimum
           curd = d;
           cur = __builtin_amdgcn_readlane(c, __ffsll((long long)eq) - 1);
@@ -541,7 +541,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         // root along its leaf-to-root path and pop_heap's sift-down retraces exactly that path (every path element is
         // strictly larger than its sibling), leaving the array as it was -- skip the emulation.
         if (hn == a.k && !heap_dup && dj > heap_root) continue;
-        heap_dup = heap_dup || __ballot((uint32_t)lane < hn && hkey == dj) != 0ull;
+        heap_dup = heap_dup || hs_ballot((uint32_t)lane < hn && hkey == dj) != 0ull;
         rh[hn++] = Pair{dj, uni(pend[j])};
         push_heap(rh, (long)hn, LessD());
         if (hn > a.k) { pop_heap(rh, (long)hn, LessD()); hn--; }
@@ -577,10 +577,10 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     bool any = false;
     // the scan of one tile of <= 64 neighbours: estimates d (lanes with act), then the buffer updates in adjacency order
     auto scan = [&](bool act, uint32_t c, float d) {
-      n_est += __popcll(__ballot(act));
+      n_est += __popcll(hs_ballot(act));
       // is_full() can only turn true as the scan proceeds (the last key never grows once the buffer is full), so
       // the pre-test with the state at the start of the tile rejects nothing the sequential scan would accept
-      unsigned long long pendm = __ballot(act && !(d > ps.last) && !set_has(tab, mask, c));
+      unsigned long long pendm = hs_ballot(act && !(d > ps.last) && !set_has(tab, mask, c));
       while (pendm) {
         const int l = __ffsll((long long)pendm) - 1;
         pendm &= pendm - 1;
@@ -605,7 +605,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         const uint32_t *r = row + (size_t)(slot < ix.tile_stride ? slot : 0) * sq.rec_words;
         const uint4 h = *reinterpret_cast<const uint4 *>(r);
         const bool act = slot < ix.tile_stride && h.w != kNoneQ;
-        if (!__ballot(act)) break;
+        if (!hs_ballot(act)) break;
         any = true;
         const float d = act ? est_rec<NBLK>(sq, planes, gadd, delta, vl, k1, r, h) : FLT_MAX;
         scan(act, h.w, d);
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(64) slimq_kernel(DevIndex ix, DevSlimQ sq, Sli
     // second pass: 64 statuses per read, then the (normally zero) flagged queries of the block one after the other
     for (uint32_t base = blockIdx.x * 64; base < a.nq; base += gridDim.x * 64) {
       const uint32_t q = base + threadIdx.x;
-      unsigned long long m = __ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
+      unsigned long long m = hs_ballot(q < a.nq && ((1u << a.status[q]) & a.select_mask));
       while (m) {
         const uint32_t qi = base + (uint32_t)__ffsll((long long)m) - 1;
         m &= m - 1;

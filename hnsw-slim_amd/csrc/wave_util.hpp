@@ -32,6 +32,16 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
 
+// Lane mask of a predicate.  HIP's __ballot(int) compares an int with zero, so a bool is first materialised in a VGPR
+// (v_cndmask + v_cmp_ne per call); the builtin takes the comparison's SGPR pair as it stands.
+__device__ __forceinline__ unsigned long long hs_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// v with lane `lane` (uniform) replaced by the uniform value x: one v_writelane instead of compare + move + select.
+__device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t x, uint32_t lane) {
+  asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(lane) : "m0");
+  return v;
+}
+
 // Minimum of v over the wave without touching LDS: inclusive min-scan inside each row of 16 lanes with DPP
 // row_shr, then the four row results (lanes 15/31/47/63) are combined through SGPRs.
 __device__ __forceinline__ float wave_min_f32(float v) {

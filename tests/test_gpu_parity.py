@@ -411,6 +411,34 @@ def test_large_batch_runs_as_launch_groups(hs, oracle, tmp_path):
     assert _pq_sorted(pq["dists"], pq["labels"], pq["cnt"]) == _pq_sorted(wq["dists"], wq["labels"], wq["cnt"])
 
 
+@pytest.mark.parametrize("metric,dim", [(L2, 32), (IP, 48)])
+def test_ordered_two_launch_pass(hs, oracle, tmp_path, metric, dim):
+    """From 6144 queries per launch the fast / lean pass runs as three launches -- upper-level descent, queries ordered by
+    the distance of their level-0 entry, level-0 search in that order: same answers and counters as the one-launch pass,
+    for both index kinds, the (q,k) overloads that tag the enter point, and the lean kernel (ef >= 192)."""
+    base = mixture(6000, dim, 91)
+    q = mixture(7000, dim, 92)
+    hp, sp = str(tmp_path / "h.bin"), str(tmp_path / "s.bin")
+    hs.build_hnsw(base, hp, metric=metric, M=8, ef_construction=60, threads=8)
+    hs.convert_slim(hp, sp, dim, metric=metric, threads=8)
+    for path, kind, okind in ((sp, hs.HS_KIND_SLIM, "slim"), (hp, hs.HS_KIND_HNSW, "hnsw")):
+        ix = hs.Index(path, kind, dim, metric)
+        ox = oracle.load(path, okind, metric, dim)
+        for ef in (24, 200):
+            ix.set_ef(ef); ox.set_ef(ef)
+            if okind == "slim":   # the id-array overload exists on the Slim class only
+                got = ix.search_ids(q, 10, want_stats=True, want_dists=True)
+                small = ix.search_ids(q[:500], 10, want_stats=True, want_dists=True)      # below the threshold: one launch
+                want = ox.search_ids(q, 10, threads=8)
+                assert np.array_equal(np.sort(got["labels"], axis=1), np.sort(want["labels"], axis=1)), (okind, ef)
+                assert np.array_equal(got["stats"][:, :3], want["counters"][:, :3]), (okind, ef)
+                assert np.array_equal(got["labels"][:500], small["labels"]) and got["dists"][:500].tobytes() == small["dists"].tobytes()
+            pq, wq = ix.search_pq(q, 10, want_stats=True), ox.search_pq(q, 10, threads=8)
+            assert np.array_equal(pq["cnt"], wq["cnt"])
+            assert np.array_equal(pq["stats"][:, :3], wq["counters"][:, :3]), (okind, ef)
+            assert _pq_sorted(pq["dists"], pq["labels"], pq["cnt"]) == _pq_sorted(wq["dists"], wq["labels"], wq["cnt"]), (okind, ef)
+
+
 def test_cpp_facade_build_then_search(hs, oracle, tmp_path):
     """A caller that BUILDS through the hnswlib API (ctor, addPoint loop, saveIndex, convertFromHNSW, saveIndex, setEf,
     searchKnn -- hnsw_strategy.h / hnsw_slim_strategy.h): the saved files are the harness's (byte-identical to the
