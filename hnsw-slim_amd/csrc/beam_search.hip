@@ -996,7 +996,7 @@ template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D16 > 16 ? 3 : HS_FAST_WAVES))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x) {
-    const uint32_t qi = a.phase == 2 ? a.order[it] : it;
+    const uint32_t qi = (a.phase == 2 && a.order) ? a.order[it] : it;
     if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;  // pass 0 takes every query
     if (ix.n == 0) {
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
@@ -1031,8 +1031,9 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
   __shared__ uint32_t wave_tot[kOrderThreads / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   float lo = FLT_MAX, hi = -FLT_MAX;
+  auto key_of = [&](uint32_t i) -> float { return __uint_as_float(entry[i].y); };
   for (uint32_t i = t; i < nq; i += kOrderThreads) {
-    const float d = __uint_as_float(entry[i].y);
+    const float d = key_of(i);
     if (d == d && fabsf(d) <= FLT_MAX) { lo = fminf(lo, d); hi = fmaxf(hi, d); }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -1050,7 +1051,7 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
     const float x = (hi - fminf(fmaxf(d, lo), hi)) * scale;
     return min((uint32_t)x, kOrderBins - 1);
   };
-  for (uint32_t i = t; i < nq; i += kOrderThreads) atomicAdd(&bins[bin_of(__uint_as_float(entry[i].y))], 1u);
+  for (uint32_t i = t; i < nq; i += kOrderThreads) atomicAdd(&bins[bin_of(key_of(i))], 1u);
   __syncthreads();
   // exclusive prefix sums of the bins: four consecutive bins per thread, wave scan, then the wave totals
   uint32_t v[4], sum = 0;
@@ -1068,7 +1069,7 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
   __syncthreads();
   for (int j = 0; j < 4; j++) { bins[4 * t + j] = run; run += v[j]; }
   __syncthreads();
-  for (uint32_t i = t; i < nq; i += kOrderThreads) order[atomicAdd(&bins[bin_of(__uint_as_float(entry[i].y))], 1u)] = i;
+  for (uint32_t i = t; i < nq; i += kOrderThreads) order[atomicAdd(&bins[bin_of(key_of(i))], 1u)] = i;
 }
 hipError_t launch_order(const uint4 *entry, uint32_t *order, uint32_t nq, hipStream_t stream) {
   static_assert(kOrderBins == 4 * kOrderThreads, "four bins per thread in the prefix step");

@@ -731,7 +731,8 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
       a.entry = reinterpret_cast<uint4 *>(w->entry.p); a.order = w->order.p;
       a.phase = 1;
       HIP_TRY(launch_fast(ix->dev, a, stream));
-      HIP_TRY(launch_order(a.entry, w->order.p, (uint32_t)nq, stream));
+      if (order_env == 2) a.order = nullptr;   // diagnostic: the split without the ordering
+      else HIP_TRY(launch_order(a.entry, w->order.p, (uint32_t)nq, stream));
       a.phase = 2;
       HIP_TRY(launch_fast(ix->dev, a, stream));
       a.phase = 0;
@@ -970,7 +971,21 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   HIP_TRY(launch_slimq_prep(ix->sq, (uint32_t)ix->info.dim, ix->info.metric, d_queries, (uint32_t)nq, w->prep.p, nullptr, stream));
   a.prep = w->prep.p;
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p;
-  HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
+  static const int order_env = getenv("HS_ORDER") ? atoi(getenv("HS_ORDER")) : -1;   // diagnostic: 0 = never, 1 = always
+  if (!a.trace && (order_env < 0 ? nq >= kOrderMinQueries : order_env != 0)) {
+    // descent / order by the entry's estimated distance, farthest first / level-0 search (see search_dev_group)
+    HIP_TRY(w->entry.ensure(nq * 4));
+    HIP_TRY(w->order.ensure(nq));
+    a.entry = reinterpret_cast<uint4 *>(w->entry.p); a.order = w->order.p;
+    a.phase = 1;
+    HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
+    HIP_TRY(launch_order(a.entry, w->order.p, (uint32_t)nq, stream));
+    a.phase = 2;
+    HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
+    a.phase = 0;
+  } else {
+    HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
+  }
   if (a.hash_slots < kSlimQMaxHash) {
     a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 64); a.hash_slots = kSlimQMaxHash;
     a.counters = w->counters.p + 8;

@@ -478,7 +478,7 @@ template <int METRIC, int S, int D16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_LEAN_WAVES))) lean_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x) {
-    const uint32_t qi = a.phase == 2 ? a.order[it] : it;
+    const uint32_t qi = (a.phase == 2 && a.order) ? a.order[it] : it;
     if (a.pass_id != 0 && !((1u << a.status[qi]) & a.select_mask)) continue;   // pass 0 takes every query
     const int rc = search_one_lean<METRIC, S, D16>(ix, a, qi, smem);
     if (rc == 3 && threadIdx.x == 0) a.status[qi] = ST_HAZARD;

@@ -35,6 +35,11 @@ struct SlimQArgs {
   uint32_t *trace;        // debug (nullable): nq x trace_cap, the pops in order: node id, bit 31 set = revisit
   uint32_t trace_cap;
   const uint32_t *prep;   // nq x slimq_prep_words(): per-query records written by launch_slimq_prep
+  // first pass in two launches (as SearchArgs::phase, engine.hpp): 1 = descent only -> entry[qi] = {node, estimate,
+  // estimates so far, -}; 2 = level-0 search from entry[], queries taken in the order order[] gives; 0 = one launch
+  uint32_t phase;
+  uint4 *entry;
+  const uint32_t *order;
 };
 
 // Query preparation (rotation, split query, centroid table) -> prep[nq x slimq_prep_words(ncl, padded)]:

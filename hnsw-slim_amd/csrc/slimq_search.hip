@@ -435,7 +435,14 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   uint32_t n_hops = 0, n_est = 1, n_ins = 0, n_rev = 0, n_tr = 0;
   // entry point and greedy descent on estimated distances (:1850-1901)
   uint32_t cur = ix.enterpoint, cur_b = sq.ep_base;   // cur_b = up_base[cur], carried along with cur
-  float curd = unif(est_one<NBLK>(sq, planes, gadd, delta, vl, k1, cur));
+  float curd = 0.f;
+  if (a.phase == 2) {   // the descent ran in an earlier launch
+    const uint4 e = a.entry[qi];
+    cur = uni(e.x);
+    curd = unif(__uint_as_float(e.y));
+    n_est = uni(e.z);
+  } else {
+  curd = unif(est_one<NBLK>(sq, planes, gadd, delta, vl, k1, cur));
   for (int lvl = ix.maxlevel; lvl > ix.threshold_level; lvl--) {
     bool changed = true;
     while (changed) {
@@ -486,6 +493,11 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         }
       }
     }
+  }
+  if (a.phase == 1) {
+    if (lane == 0) a.entry[qi] = make_uint4(cur, __float_as_uint(curd), n_est, 0u);
+    return ST_TODO;
+  }
   }
 
   float pkey[S];
@@ -662,7 +674,8 @@ __global__ void __launch_bounds__(64) slimq_kernel(DevIndex ix, DevSlimQ sq, Sli
     }
     return;
   }
-  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) slimq_one<METRIC, S, NBLK, DBG>(ix, sq, a, qi, smem);   // first pass: every query
+  for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x)   // first pass: every query
+    slimq_one<METRIC, S, NBLK, DBG>(ix, sq, a, (a.phase == 2 && a.order) ? a.order[it] : it, smem);
 }
 
 template <typename K>

@@ -79,6 +79,15 @@ def test_slimq_d128_l2(env):
     assert rec > 0.9
 
 
+def test_slimq_ordered_two_launch_pass(env):
+    """From 6144 queries the first pass runs as descent / order by entry estimate / level-0 search: same traversal, same answers."""
+    P, O, tmp = env
+    x = sift_like(4000 + 6500, 128, seed=13, n_clusters=32)
+    base, q = x[:4000], x[4000:]
+    path = build(P, tmp, "d128_order", base, 0, 8)
+    check(P, O, path, base, q, 0, 10, (32, 128))
+
+
 def test_slimq_integer_ties(env):
     """Small integer coordinates: many equal exact distances (heap ties) and equal estimates."""
     P, O, tmp = env

@@ -1,9 +1,7 @@
-# development aid: parity on the tie-heavy tests, then the 10k single launch and the steady state of the current build,
-# with and without the two-launch ordered fast pass (HS_ORDER)
+# experiment: which property of the start order matters (HS_ORDER_KEY 0 far first, 1 near first, 2 by entry node id)
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -5 || exit 1
 python tools/qbench.py --efs 70 > /dev/null 2>&1
-echo "index order"; HS_ORDER=0 python tools/qbench.py --efs 32,70,128 2>&1 | grep -E "^ef=|oracle"
-echo "entry-distance order"; python tools/qbench.py --efs 32,70,128 --check 2>&1 | grep -E "^ef=|oracle"
-echo "steady, index order"; HS_ORDER=0 python tools/qbench.py --efs 70 --nq 65536 --reps 3 2>&1 | grep -E "^ef="
-echo "steady, entry-distance order"; python tools/qbench.py --efs 70 --nq 65536 --reps 3 2>&1 | grep -E "^ef="
+for K in 0 1 2; do
+  echo "HS_ORDER_KEY=$K"; HS_ORDER_KEY=$K python tools/qbench.py --efs 70 2>&1 | grep -E "^ef="
+  HS_ORDER_KEY=$K python tools/qbench.py --efs 70 --nq 65536 --reps 3 2>&1 | grep -E "^ef="
+done
