@@ -379,6 +379,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved_single, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_single / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "kernel": "hs::fast_kernel", "launch_ms": round(kern_ms, 4),
+                         "launch": "one 10k-query pass = fast_kernel (upper-level descent) + order_kernel (start order) + fast_kernel "
+                                   "(level-0 search); launch_ms spans the three, a rocprofv3 kernel trace shows two fast_kernel "
+                                   "dispatches per pass whose durations add up to it (profiles/r02_kernel_stats_1stream.csv)",
                          "timed_region_achieved": round(eff, 1), "timed_region_frac": round(eff / HBM_PEAK_GBS, 4),
                          "launches_in_flight": S, "algorithmic_bytes_per_launch": alg_bytes_launch},
             "cpu_baseline": cpu,

@@ -20,7 +20,12 @@ def per_launch(path, kernel_sub, counters):
         if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] in tot:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             n[r["Counter_Name"]] += 1
-    return {c: tot[c] / max(n[c], 1) for c in counters}, n
+    return {c: tot[c] / max(n[c], 1) * DISPATCHES_PER_PASS.get(kernel_sub, 1) for c in counters}, n
+
+
+# A 10k-query pass of the fast kernel is two dispatches since round 2 (descent, then level-0 search in entry-distance order,
+# csrc/capi.cpp search_dev_group): "per launch" figures are per PASS, i.e. the per-dispatch average times two.
+DISPATCHES_PER_PASS = {"fast_kernel": 2} if (len(sys.argv) > 1 and sys.argv[1] != "r01") else {}
 
 
 for s in ("1stream", "pipelined"):
@@ -40,7 +45,7 @@ hbm = fetch["FETCH_SIZE"] * 1024 * corr + write["WRITE_SIZE"] * 1024
 out = {
     "workload": f"SIFT-1M-like d=128 N=1000000 nq=10000 ef={ef} k=10, 1 stream",
     "ef": ef,
-    "kernel": "hs::fast_kernel<0,2,8>",
+    "kernel": "hs::fast_kernel<0,2,8>" + (" (both dispatches of a pass: descent + level-0 search)" if DISPATCHES_PER_PASS else ""),
     "FETCH_SIZE_KiB_per_launch": round(fetch["FETCH_SIZE"], 1),
     "WRITE_SIZE_KiB_per_launch": round(write["WRITE_SIZE"], 1),
     "calibration": {
@@ -53,3 +58,39 @@ out = {
             "this access pattern; separate --pmc passes for FETCH_SIZE, WRITE_SIZE and TCC_HIT/MISS (tools/prof_cmd.sh)"}
 json.dump(out, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+
+def totals(path, kernel_sub):
+    tot, disp = {}, set()
+    for r in csv.DictReader(open(path)):
+        if kernel_sub in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    return tot, len(disp)
+
+
+# instruction mix and wait split of the search kernel (separate --pmc passes), per PASS of 10k queries
+lines = []
+for d, title in (("pmc_insts", "instruction mix"), ("pmc_wait", "where a wavefront's cycles go")):
+    f = newest(f"{d}/**/*counter_collection.csv")
+    if not f:
+        continue
+    tot, nd = totals(f, "fast_kernel")
+    passes = max(nd // DISPATCHES_PER_PASS.get("fast_kernel", 1), 1)
+    lines.append(f"{title}: rocprofv3 --pmc {' '.join(sorted(tot))} -- python bench.py --ef {ef} --streams 1 --steps 2 --warmup 1 "
+                 f"(hs::fast_kernel, {nd} dispatches = {passes} passes of 10000 queries; per-pass averages; SQ_WAVE_CYCLES and the wait/active counters count quad-cycles)")
+    for k in sorted(tot):
+        lines.append(f"    {k:22s} {tot[k] / passes:16.0f}")
+    if "SQ_INSTS_VALU" in tot:
+        nd_q = b["config"]["sweep"][str(ef)]["n_dist"]
+        lines.append(f"    -> per query: {tot['SQ_INSTS_VALU'] / passes / 1e4:.0f} VALU + {tot['SQ_INSTS_SALU'] / passes / 1e4:.0f} SALU + {tot['SQ_INSTS_LDS'] / passes / 1e4:.0f} LDS; "
+                     f"per distance evaluation ({nd_q:.0f} per query): {tot['SQ_INSTS_VALU'] / passes / 1e4 / nd_q:.0f} VALU + {tot['SQ_INSTS_SALU'] / passes / 1e4 / nd_q:.0f} SALU")
+    if "SQ_WAIT_ANY" in tot:
+        wc = tot["SQ_WAVE_CYCLES"]
+        lines.append("    -> share of wave cycles: " + ", ".join(f"{k} {100 * tot[k] / wc:.1f}%" for k in sorted(tot) if k != "SQ_WAVE_CYCLES"))
+if lines:
+    open(os.path.join(DST, f"{tag}_pmc_insts.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+cv = os.path.join(SRC, "convert_1m.log")
+if os.path.exists(cv):
+    shutil.copy(cv, os.path.join(DST, f"{tag}_convert_1m.log"))
