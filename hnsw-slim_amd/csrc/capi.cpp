@@ -680,7 +680,8 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
                      group_lds_bytes((uint32_t)ix->info.dim, sh.g_cand_cap, sh.g_hash_slots, group_q_in_regs(ix->info.metric, (uint32_t)ix->info.dim)) <= kLdsPerCU;
   // The lean kernel answers from HS_LEAN_MIN_EF upwards (diagnostic knob; default: see kLeanMinEf)
   static const uint32_t lean_min_ef = getenv("HS_LEAN_MIN_EF") ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
-  const bool lean = !group && fast && sh.ef >= lean_min_ef && lean_supported(ix->dev, sh.ef, (uint32_t)k) &&
+  static const bool lean_forced = getenv("HS_LEAN_MIN_EF") != nullptr;   // the parity tests force it on every shape it supports
+  const bool lean = !group && fast && sh.ef >= lean_min_ef && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
                     lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.l_hash_slots) <= kLdsPerCU;
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;

@@ -183,13 +183,17 @@ np.savez(sys.argv[3], **out)
     hs.build_hnsw(base, str(tmp_path / "h.bin"), M=16, ef_construction=100, threads=8)
     hs.convert_slim(str(tmp_path / "h.bin"), str(tmp_path / "s.bin"), 128, threads=8)
     res = {}
-    for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000"}), ("group", {"HS_GROUP": "1"}), ("lean", {"HS_LEAN_MIN_EF": "1"})):
+    # (the last two force the descent / order / level-0 launches of large batches, csrc/capi.cpp, onto this 300-query batch)
+    for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "0"}), ("group", {"HS_GROUP": "1"}), ("lean", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "0"}),
+                     ("fast_ordered", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "1"}), ("lean_ordered", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "1"})):
         of = str(tmp_path / f"{tag}.npz")
         subprocess.check_call([sys.executable, wf, ROOT, str(tmp_path), of], env=dict(os.environ, **env))
         res[tag] = np.load(of)
     for key in res["fast"].files:
         assert np.array_equal(res["fast"][key], res["group"][key]), key
         assert np.array_equal(res["fast"][key], res["lean"][key]), key
+        assert np.array_equal(res["fast"][key], res["fast_ordered"][key]), key
+        assert np.array_equal(res["fast"][key], res["lean_ordered"][key]), key
 
 
 def test_index_from_host_arrays_equals_index_from_file(hs, slim_file):
