@@ -311,10 +311,7 @@ __device__ __forceinline__ void descend(const DevIndex &ix, const SearchArgs &a,
   curdist = unif(nd[0]);
   c.n_dist = 1;
   c.n_hops = c.n_nbr = 0;
-  if (a.mark_ep) {  // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
-    if (lane == 0) vis_insert(vis, cur);
-    vis.n1++;
-  }
+  if (a.mark_ep) vis_mark_one(vis, cur, a, lane);  // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
   uint32_t cur_b = ix.ep_base;   // up_base[cur], carried along with cur on the tiled path
   for (int lvl = ix.maxlevel; lvl > ix.threshold_level; lvl--) {
     bool changed = true;
@@ -657,8 +654,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     c.n_nbr = c.n_dist - 1;   // the descent evaluates every neighbour it reads, plus the enter point
     if (a.mark_ep) {  // hnswalg_slim.h:1919
       wave_sync();
-      if (lane == 0) vis_insert(vis, ix.enterpoint);
-      vis.n1++;
+      vis_mark_one(vis, ix.enterpoint, a, lane);
     }
     wave_sync();
   } else {
@@ -685,12 +681,11 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   uint32_t cand_size = 0;            // heap entries physically in LDS
   unsigned long long pending = 1ull; // accepted entries of nd/nid still to be pushed (bit j = entry j)
   wave_sync();
+  const bool entry_marked = vis_mark_one(vis, cur, a, lane);  // hnswalg_slim.h:2102
   if (lane == 0) {
-    vis_insert(vis, cur);  // hnswalg_slim.h:2102
     nd[0] = next_d;
     nid[0] = cur;
   }
-  vis.n1++;
   if (ix.kind == 0 && !bare && ep_deleted) {  // hnswalg.h:359-362
     lb = FLT_MAX;
   } else {
@@ -700,7 +695,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     lb = ep_deleted ? FLT_MAX : curdist;                       // :2104-2106
   }
   const uint32_t stride = ix.tile_stride;
-  int rc = 0;
+  int rc = entry_marked ? 0 : 1;
   // ef == k: nothing is selected at the end, so a tie ACROSS the capacity boundary decides the answer -- the reference
   // evicts the root of its heap, i.e. one of several entries with the largest key, which one depends on the heap layout.
   // Whenever an evicted key equals the last kept key the logged insertions are replayed (as for the k / k+1 tie).
@@ -714,7 +709,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   // a pushed entry only rises past strictly larger parents, so it is the earliest new entry with the
   // smallest distance if that beats the old root, else the old root.  So the next node's adjacency read
   // is issued first and the very same pushes / pop run on the LDS heap while HBM is busy.
-  while (true) {
+  while (rc == 0) {
     if (__builtin_expect(cand_size == 0 && pending == 0, 0)) break;
     if (__builtin_expect(bare ? (next_d > lb) : (next_d > lb && top_size == ef), 0)) break;  // :340 / :346-347
     // the node's whole level-0 list is one aligned tile: one coalesced read from its id
@@ -734,17 +729,23 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     const bool valid = id != kNone;
     const uint32_t m = __popcll(hs_ballot(valid));
     HS_LAP(c, 1);
-    if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
     if (__builtin_expect(cand_size + m > cand_total, 0)) { rc = 2; break; }
     bool isnew = false;
-    if (valid) isnew = vis_insert(vis, id);  // :392-393
+    if (vis.qbits) {
+      bool fail = false;
+      isnew = vis_test_and_mark_q16(vis, id, valid, a, lane, fail);  // :392-393
+      if (__builtin_expect(fail, 0)) { rc = 1; break; }
+    } else {
+      if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
+      if (valid) isnew = vis_insert(vis, id);  // :392-393
+    }
     const unsigned long long nm = hs_ballot(isnew);
     const uint32_t cnt = __popcll(nm);
     c.n_nbr += m;
     wave_sync();
     if (isnew) nid[__popcll(nm & ((1ull << lane) - 1ull))] = id;  // unvisited ids, adjacency order
     wave_sync();
-    vis_commit(vis, cnt);
+    if (!vis.qbits) vis_commit(vis, cnt);
     c.n_dist += cnt;
     HS_LAP(c, 2);
     // row loads go out first; pop_heap (:353-354) re-heapifies the LDS array while they are in flight

@@ -134,6 +134,7 @@ static uint32_t next_pow2(uint32_t v) {
 
 struct Shape {
   uint32_t ef, cand_cap, cand_cap_fast, hash_slots;
+  uint32_t q_hash_slots, q_bits;        // fast kernel: visited-set tier 1 in 16-bit slots (LDS words, id-space width; 0 = not applicable)
   uint32_t g_cand_cap, g_hash_slots;    // group kernel (four queries per wavefront): per-query LDS shares
   uint32_t l_cand_cap, l_hash_slots;    // lean kernel
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
@@ -161,6 +162,21 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   // tier-1 visited set: sized so that most queries never leave LDS (75 % fill); the rest spill to tier 2
   const uint32_t want = (uint32_t)((450 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash) / 0.75);
   s.hash_slots = ix->user_hash_slots ? (ix->user_hash_slots + 63) / 64 * 64 : (want + 63) / 64 * 64;
+  // Fast kernel: the same LDS holds twice the ids as 16-bit remainders of a bijective hash, eight to a 16-byte bucket, no
+  // probing (csrc/search_common.hpp).  Buckets: a power of two with the expected number of visited ids filling them to
+  // 4.5 of 8 on average; usable while the id space is at most 16 bits wider than the bucket index.
+  {
+    const uint32_t n_vis = ix->user_hash_slots ? ix->user_hash_slots : (uint32_t)((450 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash));
+    uint32_t nb = 4;
+    while (nb * 4.5 < n_vis && nb < (1u << 14)) nb <<= 1;
+    uint32_t bbits = 0, idbits = 1;
+    while ((1u << bbits) < nb) bbits++;
+    while (idbits < 32 && ((uint64_t)1 << idbits) < (uint64_t)std::max<size_t>(ix->info.n, 2)) idbits++;
+    const uint32_t B = std::max(idbits, bbits);
+    static const bool off = getenv("HS_VIS16") && atoi(getenv("HS_VIS16")) == 0;   // diagnostic: the 32-bit form everywhere
+    s.q_hash_slots = nb * 4;
+    s.q_bits = (!off && B - bbits <= 16 && B < 32) ? B : 0;
+  }
   const uint32_t dim = (uint32_t)ix->info.dim;
   // Group kernel: LDS is what bounds the queries resident per CU, so the shares cover most queries (candidate heap: ~p99 of
   // the peak size, visited set: ~p90 of the distance evaluations, measured on the 1M SIFT-like bench index for ef 32..256)
@@ -671,8 +687,15 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
   a.status = w->status.p;
   a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
+  const uint32_t fast_hash = sh.q_bits ? sh.q_hash_slots : sh.hash_slots;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
-                    fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, sh.hash_slots) <= kLdsPerCU;
+                    fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, fast_hash) <= kLdsPerCU;
+  // scratch shares of the fast kernel's launches / of everything else
+  auto fast_scratch = [&](bool on) {
+    a.cand_cap = on ? sh.cand_cap_fast : sh.cand_cap;
+    a.hash_slots = on ? fast_hash : sh.hash_slots;
+    a.vis_bits = on ? sh.q_bits : 0;
+  };
   // The four-queries-per-wavefront kernel (group_search.hip) is parity-green but measured slower than the one-query-per-wave
   // fast kernel on MI355X: HS_GROUP=1 selects it for A/B runs and for its parity tests.
   static const bool use_group = getenv("HS_GROUP") != nullptr;
@@ -713,13 +736,13 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     HIP_TRY(launch_group(ix->dev, a, stream));
     a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots;
     if (fast) {
-      a.cand_cap = sh.cand_cap_fast;
+      fast_scratch(true);
       a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.pass_id = 3;
       HIP_TRY(launch_fast(ix->dev, a, stream));
-      a.cand_cap = sh.cand_cap;
+      fast_scratch(false);
     }
   } else {
-    if (fast) a.cand_cap = sh.cand_cap_fast;
+    if (fast) fast_scratch(true);
     // pass 0: every query, one wavefront each
     a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
     // A launch much larger than what the GPU holds at once (4096 wavefronts of this kernel) ends on the queries that
@@ -740,6 +763,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     } else {
       HIP_TRY(fast ? launch_fast(ix->dev, a, stream) : launch_strict(ix->dev, a, stream));
     }
+    fast_scratch(false);
   }
   // Both re-run passes are normally empty (a launch that scans the statuses and exits), so they share one launch whenever
   // the whole-CU pass exists: a batch is then two kernel launches, not three.

@@ -54,6 +54,8 @@ struct SearchArgs {
   uint32_t pass_id;
   uint32_t *queue;       // group kernel: device-wide query counter (zeroed per launch group)
   uint32_t hash_fill_shift;   // visited-set tier 1 is frozen at 1 - 2^-shift of its slots (0 = the default 2: 75 %)
+  uint32_t vis_bits;     // fast kernel: 0 = visited-set tier 1 in 32-bit slots; else the width of the id space for the
+                         // 16-bit form (search_common.hpp; hash_slots / 4 buckets, a power of two, vis_bits - log2(buckets) <= 16)
   // Fast kernel in two launches (see launch_order): phase 1 stops after the upper-level descent and leaves
   // {level-0 entry node, its distance, n_dist, n_hops} in entry[qi]; phase 2 takes its queries in the order order[] gives
   // and starts each from its entry.  phase 0: one launch does both, in index order.

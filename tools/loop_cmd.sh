@@ -1,7 +1,7 @@
-# experiment: which property of the start order matters (HS_ORDER_KEY 0 far first, 1 near first, 2 by entry node id)
+# development A/B: visited-set tier 1 in 16-bit slots (default) against the 32-bit form (HS_VIS16=0)
 cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_patch.py -x -q 2>&1 | tail -3 || exit 1
 python tools/qbench.py --efs 70 > /dev/null 2>&1
-for K in 0 1 2; do
-  echo "HS_ORDER_KEY=$K"; HS_ORDER_KEY=$K python tools/qbench.py --efs 70 2>&1 | grep -E "^ef="
-  HS_ORDER_KEY=$K python tools/qbench.py --efs 70 --nq 65536 --reps 3 2>&1 | grep -E "^ef="
+for V in 0 1; do
+  for NQ in 1250 10000 65536; do echo "HS_VIS16=$V nq=$NQ"; HS_VIS16=$V python tools/qbench.py --efs 32,70,128 --nq $NQ --reps 4 --check 2>&1 | grep -E "^ef=|oracle: label sets equal False"; done
 done

@@ -17,7 +17,7 @@ from hsutil import headline_data, load_product  # noqa: E402
 hs = load_product()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 efs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128]
-NQ, K, D = 10000, 10, 128
+NQ, K, D = int(os.environ.get("NQ", "10000")), 10, 128
 dev = torch.device("cuda", 0)
 base = headline_data(N, D, 123)
 q = headline_data(NQ, D, 456)
