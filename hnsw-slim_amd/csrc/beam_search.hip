@@ -680,12 +680,11 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   uint32_t next_id = cur;
   uint32_t cand_size = 0;            // heap entries physically in LDS
   unsigned long long pending = 1ull; // accepted entries of nd/nid still to be pushed (bit j = entry j)
+  // accepted entries of the previous expansion, lane j = entry j, until they are pushed (see the loop)
+  float prev_d = next_d;
+  uint32_t prev_id = cur;
   wave_sync();
   const bool entry_marked = vis_mark_one(vis, cur, a, lane);  // hnswalg_slim.h:2102
-  if (lane == 0) {
-    nd[0] = next_d;
-    nid[0] = cur;
-  }
   if (ix.kind == 0 && !bare && ep_deleted) {  // hnswalg.h:359-362
     lb = FLT_MAX;
   } else {
@@ -704,32 +703,25 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   bool boundary_tie = false;
 
   // ---- level-0 beam (hnswalg_slim.h:321-457) -----------------------------------------------------
-  // The reference pushes accepted neighbours into candidate_set one by one and pops its root at the top
-  // of the next iteration.  Which entry that root will be is known as soon as the accept decisions are:
-  // a pushed entry only rises past strictly larger parents, so it is the earliest new entry with the
-  // smallest distance if that beats the old root, else the old root.  So the next node's adjacency read
-  // is issued first and the very same pushes / pop run on the LDS heap while HBM is busy.
+  // The reference pushes accepted neighbours into candidate_set one by one and pops its root at the top of the next
+  // iteration.  Which entry that root will be does not need the accept pass at all: a pushed entry only rises past
+  // strictly larger parents, so it is the earliest neighbour with the smallest distance -- accepted iff it passes the
+  // bound as it stood before this expansion, every earlier neighbour being strictly farther -- if that beats the old
+  // root, else the old root.  So one expansion runs as
+  //   visited lookups | row loads, under them: last expansion's pushes, then the pop (:353-354), on the LDS heap |
+  //   distances | next node chosen, its adjacency tile requested | accept pass (:403-452) under that read.
+  // Neither HBM round trip of an expansion waits for heap work and the heap work waits for neither.
+  uint32_t id = kNone;   // adjacency tile of the node to expand: one aligned, coalesced read from its id
+  if (rc == 0 && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
   while (rc == 0) {
     if (__builtin_expect(cand_size == 0 && pending == 0, 0)) break;
     if (__builtin_expect(bare ? (next_d > lb) : (next_d > lb && top_size == ef), 0)) break;  // :340 / :346-347
-    // the node's whole level-0 list is one aligned tile: one coalesced read from its id
-    uint32_t id = kNone;
-    if ((uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
     c.n_hops++;
-    // pending pushes of the previous expansion (:408-411), in adjacency order, under the tile read
-    wave_sync();
-    while (pending) {
-      const int j = __ffsll((long long)pending) - 1;
-      pending &= pending - 1;
-      cand_size++;
-      cand_push(cand, cand_size, unif(nd[j]), uni(nid[j]), lane);
-      wave_sync();
-    }
     HS_LAP(c, 0);
     const bool valid = id != kNone;
     const uint32_t m = __popcll(hs_ballot(valid));
     HS_LAP(c, 1);
-    if (__builtin_expect(cand_size + m > cand_total, 0)) { rc = 2; break; }
+    if (__builtin_expect(cand_size + (uint32_t)__popcll(pending) > cand_total, 0)) { rc = 2; break; }   // room for this round's pushes
     bool isnew = false;
     if (vis.qbits) {
       bool fail = false;
@@ -748,23 +740,49 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
     if (!vis.qbits) vis_commit(vis, cnt);
     c.n_dist += cnt;
     HS_LAP(c, 2);
-    // row loads go out first; pop_heap (:353-354) re-heapifies the LDS array while they are in flight
-    auto pop_hook = [&]() {
+    // row loads go out first; the pushes of the previous expansion (:408-411, adjacency order) and pop_heap (:353-354)
+    // work on the LDS heap while they are in flight
+    auto heap_hook = [&]() {
+      while (pending) {
+        const int j = __ffsll((long long)pending) - 1;
+        pending &= pending - 1;
+        cand_size++;
+        cand_push(cand, cand_size, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(prev_d), j)),
+                  __builtin_amdgcn_readlane(prev_id, j), lane);
+        wave_sync();
+      }
       if (lane == 0) cand_pop(cand, cand_size);
     };
     if (__builtin_expect(cnt > 0, 1)) {
-      wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane, pop_hook);  // :395-396
+      wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane, heap_hook);  // :395-396
     } else {
-      pop_hook();
+      heap_hook();
     }
     cand_size--;
     wave_sync();
     HS_LAP(c, 3);
     const float my_d = (uint32_t)lane < cnt ? nd[lane] : FLT_MAX;
     const uint32_t my_id = (uint32_t)lane < cnt ? nid[lane] : 0;
-    float best_d = FLT_MAX;
-    uint32_t best_id = 0;
-    bool have_best = false;
+    {
+      // root of candidate_set once this expansion's pushes are in: the nearest new neighbour if it is accepted and
+      // strictly nearer than the heap's root, else that root
+      const float best_d = wave_min_f32(my_d);
+      const bool have_best = cnt > 0 && (top_size < ef || lb > best_d);
+      bool have_next = have_best;
+      if (cand_size > 0) {
+        const uint2 root = cand.lds[1];
+        next_d = unif(__uint_as_float(root.x));
+        next_id = uni(root.y);
+        have_next = true;
+      }
+      if (have_best && (cand_size == 0 || best_d < next_d)) {
+        const int bl = __ffsll((long long)hs_ballot((uint32_t)lane < cnt && my_d == best_d)) - 1;
+        next_d = best_d;
+        next_id = __builtin_amdgcn_readlane(my_id, bl);
+      }
+      id = kNone;
+      if (have_next && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
+    }
     if (__builtin_expect(bare, 1)) {
       // ---- accept decisions (:403-452) for the whole tile at once --------------------------------------------
       // The reference scans the new neighbours in adjacency order, accepting j iff top_size < ef || lowerBound > d_j
@@ -831,13 +849,8 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         wave_sync();
         lb = top_key_at<S>(tk, top_size - 1);  // :450-452
         if (watch_boundary && old_size + n_acc > ef) boundary_tie = boundary_tie || wave_min_f32(dropped) == lb;
-        pending |= am;
+        pending = am;
         if (am) {
-          // the earliest accepted entry with the smallest distance is the one no accepted entry precedes in (d, j) order
-          const int bl = __ffsll((long long)hs_ballot(acc && Bp == 0)) - 1;
-          best_d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), bl));
-          best_id = __builtin_amdgcn_readlane(my_id, bl);
-          have_best = true;
           if (__builtin_expect(tlog != nullptr, 1) && acc) {
             const uint32_t at = n_log + __popcll(am & ((1ull << lane) - 1ull));
             if (at < a.log_cap) tlog[at] = make_uint2(__float_as_uint(my_d), my_id);
@@ -856,7 +869,6 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
       if (top_size < ef || lb > d) {  // :403-404
         const uint32_t nb = __builtin_amdgcn_readlane(my_id, j);
         pending |= 1ull << j;
-        if (!have_best || d < best_d) { best_d = d; best_id = nb; have_best = true; }
         if (bare || uni(ix.deleted[nb]) == 0) {
           const bool evicts = top_size == ef;
           const float evicted = evicts ? top_key_at<S>(tk, ef - 1) : 0.f;   // d < this key (strict), so it is the one dropped
@@ -869,16 +881,8 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
       }
     }
     }  // !bare
-    // root of candidate_set after the pending pushes
-    if (cand_size > 0) {
-      const uint2 root = cand.lds[1];
-      next_d = unif(__uint_as_float(root.x));
-      next_id = uni(root.y);
-      if (have_best && best_d < next_d) { next_d = best_d; next_id = best_id; }
-    } else if (have_best) {
-      next_d = best_d;
-      next_id = best_id;
-    }
+    prev_d = my_d;
+    prev_id = my_id;
     HS_LAP(c, 4);
   }
   if (__builtin_expect(rc != 0, 0)) {
