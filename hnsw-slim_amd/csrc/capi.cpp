@@ -705,14 +705,14 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   static const uint32_t lean_min_ef = getenv("HS_LEAN_MIN_EF") ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
   static const bool lean_forced = getenv("HS_LEAN_MIN_EF") != nullptr;   // the parity tests force it on every shape it supports
   const bool lean = !group && fast && sh.ef >= lean_min_ef && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
-                    lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.l_hash_slots) <= kLdsPerCU;
+                    lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots) <= kLdsPerCU;
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
   static const int order_env = getenv("HS_ORDER") ? atoi(getenv("HS_ORDER")) : -1;   // diagnostic: 0 = never, 1 = always
   const bool ordered = fast && !group && (order_env < 0 ? nq >= kOrderMinQueries : order_env != 0);
   if (lean) {
     // pass 0: the lean kernel; a query that exhausts even its tier-2 regions is left ST_OVERFLOW for the passes below
-    a.cand_cap = sh.l_cand_cap; a.hash_slots = sh.l_hash_slots; a.hash_fill_shift = 3;
+    a.cand_cap = sh.l_cand_cap; a.hash_slots = sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots; a.hash_fill_shift = 3; a.vis_bits = sh.q_bits;
     a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
     if (ordered) {   // descent / order / level-0 search, as for the fast kernel below
       HIP_TRY(w->entry.ensure(nq * 4));
@@ -727,7 +727,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     } else {
       HIP_TRY(launch_lean(ix->dev, a, stream));
     }
-    a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.hash_fill_shift = 0;
+    a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.hash_fill_shift = 0; a.vis_bits = 0;
   } else if (group) {
     // pass 0: the group kernel (four queries per wavefront, persistent grid) answers every query; one whose scratch runs
     // out even in its tier-2 regions is left ST_OVERFLOW for the one-query-per-wave kernels below

@@ -176,11 +176,6 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
   float curdist = 0.f;
   if (a.phase == 2) {
     // the descent ran in an earlier launch (SearchArgs::phase): its result and its counters come from entry[]
-    if (a.mark_ep) {   // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
-      wave_sync();
-      if (lane == 0) vis_insert(vis, cur);
-      vis.n1++;
-    }
     const uint4 e = a.entry[qi];
     cur = uni(e.x);
     curdist = unif(__uint_as_float(e.y));
@@ -191,10 +186,6 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
   if (lane == 0) nid[0] = cur;
   wave_sync();
   curdist = unif(wave_dists8<METRIC, D16>(ix.vec, dim, qv, nid, 1, lane, NoHook8()));
-  if (a.mark_ep) {   // visited_array[enterpoint] = tag (hnswalg_slim.h:1919)
-    if (lane == 0) vis_insert(vis, cur);
-    vis.n1++;
-  }
   uint32_t cur_b = ix.ep_base;
   for (int lvl = ix.maxlevel; lvl > 0; lvl--) {
     bool changed = true;
@@ -245,8 +236,23 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
   float next_d = curdist;
   uint32_t next_id = cur;
   wave_sync();
-  if (lane == 0) { vis_insert(vis, cur); tlog[0] = make_uint2(__float_as_uint(curdist), cur); }   // :2100-2102
-  vis.n1++;
+  // visited_array[enterpoint] = tag of the (q,k) overloads (:1919; nothing reads the set before level 0, so it is marked here)
+  // and visited_array[currObj] = tag (:2100-2102), in ONE place: lane 0 marks the entry, lane 1 the enter point.  (Three
+  // inlined copies of the 16-bit set's code make this compiler emit an illegal V_CMP against src_shared_base for the kernel.)
+  bool entry_marked = true;
+  {
+    const bool mine = lane == 0 || (lane == 1 && a.mark_ep);
+    const uint32_t mid = lane == 0 ? cur : ix.enterpoint;
+    if (vis.qbits) {
+      bool fail = false;
+      vis_test_and_mark_q16(vis, mid, mine, a, lane, fail);
+      entry_marked = !fail;
+    } else {
+      if (mine) vis_insert(vis, mid);
+      vis.n1 += a.mark_ep ? 2u : 1u;
+    }
+  }
+  if (lane == 0) tlog[0] = make_uint2(__float_as_uint(curdist), cur);
   {   // top_candidates = {(curdist, cur)}
     const int kc = fkey(curdist);
     if (lane == 0) {
@@ -260,8 +266,8 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
     lb_key = wave_max_i32(tk[0]);
   }
   const uint32_t stride = ix.tile_stride;
-  int rc = 0;
-  while (true) {
+  int rc = entry_marked ? 0 : 1;
+  while (rc == 0) {
     if (__builtin_expect(cand_size == 0 && pending == 0, 0)) break;
     if (__builtin_expect(fkey(next_d) > (n_acc >= ef ? lb_key : rmax_key), 0)) break;   // :340 candidate distance > lowerBound
     uint32_t id = kNone;
@@ -281,17 +287,23 @@ __device__ int search_one_lean(const DevIndex &ix, const SearchArgs &a, const ui
     }
     const bool valid = id != kNone;
     const uint32_t m = __popcll(hs_ballot(valid));
-    if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
     if (__builtin_expect(cand_size + m > cand_total, 0)) { rc = 2; break; }
     bool isnew = false;
-    if (valid) isnew = vis_insert(vis, id);   // :392-393
+    if (vis.qbits) {
+      bool fail = false;
+      isnew = vis_test_and_mark_q16(vis, id, valid, a, lane, fail);   // :392-393
+      if (__builtin_expect(fail, 0)) { rc = 1; break; }
+    } else {
+      if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
+      if (valid) isnew = vis_insert(vis, id);   // :392-393
+    }
     const unsigned long long nm = hs_ballot(isnew);
     const uint32_t cnt = __popcll(nm);
     n_nbr += m;
     wave_sync();
     if (isnew) nid[__popcll(nm & ((1ull << lane) - 1ull))] = id;   // unvisited ids, adjacency order
     wave_sync();
-    vis_commit(vis, cnt);
+    if (!vis.qbits) vis_commit(vis, cnt);
     n_dist += cnt;
     // row loads go out first; pop_heap (:353-354) re-heapifies the LDS array while they are in flight
     auto pop_hook = [&]() {

@@ -92,7 +92,7 @@ __device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
     if (e == -2) return false;
     if (e >= 0) {
       if (__builtin_expect(v.spilled, 0)) break;  // tier 1 is frozen: the id is not in it
-      const uint32_t old = atomicCAS(&v.t1[b * 4 + e], kEmpty, id);
+      const uint32_t old = lds_cas(&v.t1[b * 4 + e], kEmpty, id);
       if (__builtin_expect(old == kEmpty, 1)) return true;
       if (old == id) return false;
       continue;  // another lane of this wave took the slot: look at the bucket again
@@ -131,14 +131,13 @@ __device__ __forceinline__ bool vis_test_and_mark_q16(Visited &v, uint32_t id, b
     const uint32_t e = 8u - nfree;
     const uint32_t wd = (e >> 1) == 0 ? w.x : (e >> 1) == 1 ? w.y : (e >> 1) == 2 ? w.z : w.w;
     const uint32_t nw = (e & 1u) ? ((wd & 0x0000FFFFu) | (tag << 16)) : ((wd & 0xFFFF0000u) | tag);
-    const uint32_t got = atomicCAS(&v.t1[b * 4 + (e >> 1)], wd, nw);
+    const uint32_t got = lds_cas(&v.t1[b * 4 + (e >> 1)], wd, nw);
     if (got == wd) { isnew = true; break; }
     // another lane of this wave changed the word: look at the bucket again
   }
   const unsigned long long m2 = hs_ballot(t2);
   if (__builtin_expect(m2 != 0, 0)) {
-    if (!v.spilled) {
-      if (!v.t2) { fail = true; return false; }
+    if (!v.spilled) {   // (the launches that use this form always come with a tier-2 region: SearchArgs::spill)
       for (uint32_t i = lane; i < v.slots2; i += 64) v.t2[i] = kEmpty;
       __threadfence_block();
       v.spilled = true;

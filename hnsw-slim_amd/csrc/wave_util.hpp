@@ -42,6 +42,16 @@ __device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t x, uint32_t 
   return v;
 }
 
+// Compare-and-swap on a word of LDS, addressed through a generic pointer (its low half is the LDS address).  Written as the DS
+// instruction itself: an atomic on a generic pointer is expanded with is-shared / is-private tests of the address, and where this
+// compiler only half-proves that the pointer is LDS it folds such a test into an illegal V_CMP against src_shared_base.
+__device__ __forceinline__ uint32_t lds_cas(uint32_t *p, uint32_t expected, uint32_t desired) {
+  const uint32_t addr = (uint32_t)(uintptr_t)p;
+  uint32_t old;
+  asm volatile("ds_cmpst_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(expected), "v"(desired) : "memory");
+  return old;
+}
+
 // Minimum of v over the wave without touching LDS: inclusive min-scan inside each row of 16 lanes with DPP
 // row_shr, then the four row results (lanes 15/31/47/63) are combined through SGPRs.
 __device__ __forceinline__ float wave_min_f32(float v) {
