@@ -994,11 +994,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
   }
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
-#ifndef HS_FAST_WAVES
-#define HS_FAST_WAVES 4
-#endif
+// Wavefronts per SIMD the register allocation aims at.  A wavefront alone on a CU is only 25 % faster per expansion than one
+// of sixteen (tools/profile_phases.py), so residency is what pays -- as long as it costs neither spills nor LDS: the short-row
+// compile-time shapes with a result set of up to 128 entries fit 96 VGPRs with at most a few spilled dwords outside the hot loop
+// (5 waves: +6 % at ef=70, +12 % at ef=32 on a 65k-query call); the runtime-dim kernels and the wide result sets do not (128-628 B
+// of scratch at 96 VGPRs) and are bound by their LDS share anyway; long rows keep 30 loads in flight in 168 VGPRs, and so
+// does the any-dim kernel with a wide result set (it would spill 370-460 B at 128).
+__host__ __device__ constexpr int fast_waves(int d16, int s) {
+  return (d16 > 16 || (d16 == -1 && s >= 4)) ? 3 : ((d16 == 4 || d16 == 6 || d16 == 8 || d16 == 16) && s <= 2) ? 5 : 4;
+}
 template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D16 > 16 ? 3 : HS_FAST_WAVES))) fast_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fast_waves(D16, S)))) fast_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x) {
     const uint32_t qi = (a.phase == 2 && a.order) ? a.order[it] : it;
