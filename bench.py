@@ -349,7 +349,7 @@ def main():
     if rank == 0:
         # HBM traffic (PMC) cannot be collected from inside this process; the committed profile of this same workload is quoted
         traffic, tsrc = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r02_traffic.json", "r02_traffic_ef70.json", "r01_traffic.json"):   # (the operating point is 68 or 70 depending on the graph the box built)
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and N == 1_000_000 and NQ == 10_000 and D == 128 and chosen == json.load(open(tpath)).get("ef"):
                 traffic, tsrc = json.load(open(tpath))["hbm_bytes_per_launch"], "profiles/" + name

@@ -995,13 +995,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) st
 }
 // Fast kernel.  rc 3 = a tie had to be resolved but the insertion log did not fit: left to the strict pass.
 // Wavefronts per SIMD the register allocation aims at.  A wavefront alone on a CU is only 25 % faster per expansion than one
-// of sixteen (tools/profile_phases.py), so residency is what pays -- as long as it costs neither spills nor LDS: the short-row
-// compile-time shapes with a result set of up to 128 entries fit 96 VGPRs with at most a few spilled dwords outside the hot loop
-// (5 waves: +6 % at ef=70, +12 % at ef=32 on a 65k-query call); the runtime-dim kernels and the wide result sets do not (128-628 B
-// of scratch at 96 VGPRs) and are bound by their LDS share anyway; long rows keep 30 loads in flight in 168 VGPRs, and so
-// does the any-dim kernel with a wide result set (it would spill 370-460 B at 128).
+// of sixteen (tools/profile_phases.py), so residency pays -- but only while it costs neither spills nor LDS.  At 96 VGPRs
+// (5 waves) the short-row shapes spill 12-40 B per lane: +6 % on one 65k-query call, but once a kernel needs scratch the
+// batches of several streams no longer overlap cleanly and the pipelined rate DROPS 8 % (8.4 -> 7.8 M q/s, same box,
+// profiles/r02_ordered_pass_experiments.log), so the shipped value is 4 (-DHS_SHORT_WAVES=5 for the experiment).  Long rows keep
+// 30 loads in flight in 168 VGPRs (3 waves), and so does the any-dim kernel with a wide result set.
+#ifndef HS_SHORT_WAVES
+#define HS_SHORT_WAVES 4
+#endif
 __host__ __device__ constexpr int fast_waves(int d16, int s) {
-  return (d16 > 16 || (d16 == -1 && s >= 4)) ? 3 : ((d16 == 4 || d16 == 6 || d16 == 8 || d16 == 16) && s <= 2) ? 5 : 4;
+  return (d16 > 16 || (d16 == -1 && s >= 4)) ? 3 : ((d16 == 4 || d16 == 6 || d16 == 8 || d16 == 16) && s <= 2) ? HS_SHORT_WAVES : 4;
 }
 template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fast_waves(D16, S)))) fast_kernel(DevIndex ix, SearchArgs a) {

@@ -110,6 +110,7 @@ __device__ __forceinline__ bool vis_insert(const Visited &v, uint32_t id) {
 // remaining B - log2(buckets) <= 16 bits are stored, eight to a 16-byte bucket, 0xFFFF = free.  There is no probing: a
 // bucket that is full sends ITS later arrivals to tier 2 (the 32-bit table in global memory) and nobody else's, and a lookup
 // reads one bucket, plus tier 2 only if that bucket is full.  Exact like the other form: an id is in exactly one place.
+static constexpr uint32_t kQ16SpillCount = 128;
 __device__ __forceinline__ uint32_t zero_halves(uint32_t x) { return (x - 0x00010001u) & ~x & 0x80008000u; }
 // Wave-level test-and-mark of one id per lane (valid lanes).  Returns true in the lanes whose id was new; `fail` is set
 // (wave-uniformly) when tier 2 is needed and missing or exhausted.
@@ -141,11 +142,14 @@ __device__ __forceinline__ bool vis_test_and_mark_q16(Visited &v, uint32_t id, b
       for (uint32_t i = lane; i < v.slots2; i += 64) v.t2[i] = kEmpty;
       __threadfence_block();
       v.spilled = true;
-      if (lane == 0) atomicAdd(a.counters + 3, 1u);
     }
     if (v.n2 + (uint32_t)__popcll(m2) > v.limit2) { fail = true; return false; }
     if (t2) isnew = vis_insert_t2(v, id, h32);
+    // (the spill counter feeds hs_search_check's sizing rule: here a query counts once a real share of its ids lives in tier 2,
+    //  not when one full bucket sends its first id there)
+    const uint32_t before = v.n2;
     v.n2 += __popcll(hs_ballot(t2 && isnew));
+    if (before < kQ16SpillCount && v.n2 >= kQ16SpillCount && lane == 0) atomicAdd(a.counters + 3, 1u);
   }
   return isnew;
 }
