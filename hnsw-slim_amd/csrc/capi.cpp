@@ -164,11 +164,12 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   s.hash_slots = ix->user_hash_slots ? (ix->user_hash_slots + 63) / 64 * 64 : (want + 63) / 64 * 64;
   // Fast kernel: the same LDS holds twice the ids as 16-bit remainders of a bijective hash, eight to a 16-byte bucket, no
   // probing (csrc/search_common.hpp).  Buckets: a power of two with the expected number of visited ids filling them to
-  // 4.5 of 8 on average; usable while the id space is at most 16 bits wider than the bucket index.
+  // 5 of 8 on average (4.5 would double the table at ef=384 for nothing: measured); usable while the id space is at most 16 bits
+  // wider than the bucket index.
   {
     const uint32_t n_vis = ix->user_hash_slots ? ix->user_hash_slots : (uint32_t)((450 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash));
     uint32_t nb = 4;
-    while (nb * 4.5 < n_vis && nb < (1u << 14)) nb <<= 1;
+    while (nb * 5.0 < n_vis && nb < (1u << 14)) nb <<= 1;
     uint32_t bbits = 0, idbits = 1;
     while ((1u << bbits) < nb) bbits++;
     while (idbits < 32 && ((uint64_t)1 << idbits) < (uint64_t)std::max<size_t>(ix->info.n, 2)) idbits++;
