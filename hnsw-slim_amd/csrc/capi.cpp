@@ -689,6 +689,23 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
   a.status = w->status.p;
   a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
+  // A launch that cannot fill the GPU anyway (fewer queries than wavefront slots) lasts as long as its longest query, and
+  // LDS is not what limits it: the 16-bit visited set then takes up to 4x the buckets, as far as the queries of this launch
+  // still all fit on the chip at once -- the longest queries never see a full bucket.
+  if (sh.q_bits && !ix->user_hash_slots) {
+    const size_t waves_per_cu = std::max<size_t>((nq + 255) / 256, 1);
+    const size_t budget = std::min<size_t>(kLdsPerCU / waves_per_cu, 64 * 1024);
+    uint32_t bbits = 0;
+    while ((1u << bbits) < sh.q_hash_slots / 4) bbits++;
+    for (int step = 0; step < 2; step++) {
+      const uint32_t bigger = sh.q_hash_slots * 2;
+      const size_t lds_fast = fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, bigger);
+      const size_t lds_lean = lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, bigger);
+      if (std::max(lds_fast, lds_lean) > budget || bbits + 1 > sh.q_bits) break;
+      sh.q_hash_slots = bigger;
+      bbits++;
+    }
+  }
   const uint32_t fast_hash = sh.q_bits ? sh.q_hash_slots : sh.hash_slots;
   const bool fast = !ix->exact_order && !raw && fast_supported(ix->dev, sh.ef, (uint32_t)k) &&
                     fast_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.cand_cap_fast, fast_hash) <= kLdsPerCU;
