@@ -160,7 +160,8 @@ def test_group_kernel_parity_under_env(hs, tmp_path):
     """The four-queries-per-wavefront kernel (group_search.hip; HS_GROUP=1, off by default because it measured slower) and the lean
     kernel (lean_search.hip; serves ef >= 192 by default, forced for every ef here):
     same labels, distances and counters as the fast kernel on tie-heavy integer data and on a tie-free graph, with
-    starved scratch (tier-2 visited set / candidate heap) as well."""
+    starved scratch (tier-2 visited set / candidate heap) as well; likewise the ordered three-launch pass and the 32-bit form of
+    the visited set, each forced by its environment knob."""
     code = r'''
 import os, sys, numpy as np
 sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
@@ -185,7 +186,9 @@ np.savez(sys.argv[3], **out)
     res = {}
     # (the last two force the descent / order / level-0 launches of large batches, csrc/capi.cpp, onto this 300-query batch)
     for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "0"}), ("group", {"HS_GROUP": "1"}), ("lean", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "0"}),
-                     ("fast_ordered", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "1"}), ("lean_ordered", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "1"})):
+                     ("fast_ordered", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "1"}), ("lean_ordered", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "1"}),
+                     # the visited set's 32-bit form (what an index beyond 2^(log2(buckets)+16) nodes gets) instead of the 16-bit one
+                     ("fast_vis32", {"HS_LEAN_MIN_EF": "100000", "HS_VIS16": "0"}), ("lean_vis32", {"HS_LEAN_MIN_EF": "1", "HS_VIS16": "0"})):
         of = str(tmp_path / f"{tag}.npz")
         subprocess.check_call([sys.executable, wf, ROOT, str(tmp_path), of], env=dict(os.environ, **env))
         res[tag] = np.load(of)
@@ -194,6 +197,8 @@ np.savez(sys.argv[3], **out)
         assert np.array_equal(res["fast"][key], res["lean"][key]), key
         assert np.array_equal(res["fast"][key], res["fast_ordered"][key]), key
         assert np.array_equal(res["fast"][key], res["lean_ordered"][key]), key
+        assert np.array_equal(res["fast"][key], res["fast_vis32"][key]), key
+        assert np.array_equal(res["fast"][key], res["lean_vis32"][key]), key
 
 
 def test_index_from_host_arrays_equals_index_from_file(hs, slim_file):
