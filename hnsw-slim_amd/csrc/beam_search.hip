@@ -616,8 +616,21 @@ __device__ __forceinline__ void top_insert(float (&tk)[S], uint32_t (&ti)[S], ui
   size = min(size + 1, ef);
 }
 
-template <int METRIC, int S, int D16, bool WB = false, bool BARE = true>
+// FLAT (indexes without delete marks / filter; not the ef == k variant): the level-0 search starts WITHOUT a candidate heap.
+// With nothing deleted every accepted neighbour enters the result set, so candidate_set \ top_candidates only ever holds
+// entries the result set has evicted -- entries at or beyond lowerBound, which the loop condition (:340) never lets the
+// reference expand unless they tie with it.  The node to expand next is then the nearest entry of the result set that has
+// not been expanded: one flag bit per entry (bit 31 of its id) and a ballot replace the heap's pushes and pop, a third of
+// what an expansion costs a wavefront.  What the heap's LAYOUT decides in the reference is only the order among candidates
+// at EQUAL distance; the two ways that can matter are watched -- (a) the chosen node shares its distance with another
+// unexpanded entry, (b) an entry is evicted at exactly the new lowerBound (still expandable in the reference) -- and when
+// one shows, the reference's heap is materialised as it stands at that moment: the logged result-set insertions are its
+// pushes, one byte per expansion says how many belong to each, and they are replayed with the pops in between through the
+// same libstdc++ mechanics; the search then continues on the heap path.  Continuous data never leaves the flat path, integer
+// data (SIFT) does in about a quarter of the queries at ef=70, and pays then what the heap would have cost it anyway.
+template <int METRIC, int S, int D16, bool WB = false, bool BARE = true, bool FLAT = false>
 __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const uint32_t qi, unsigned char *smem) {
+  static_assert(!FLAT || (BARE && !WB), "the flat start needs an index without delete marks and ef > k");
   const int lane = threadIdx.x;
   const FastLds L = fast_layout(ix.dim, a.ef, a.cand_cap, a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
@@ -702,6 +715,91 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   constexpr bool watch_boundary = WB;
   bool boundary_tie = false;
 
+  // ---- accept decisions (:403-452) for the whole tile at once (indexes without delete marks) -------------------------
+  // Returns the number of accepted neighbours; `pending` = their lanes; drop_tie: an entry left the set at exactly the new bound.
+  uint32_t last_acc = 0;
+  bool drop_tie = false;
+  auto accept_bare = [&](const float my_d, const uint32_t my_id, const uint32_t cnt, const bool want_drop) {
+    last_acc = 0;
+    drop_tie = false;
+      // ---- accept decisions (:403-452) for the whole tile at once --------------------------------------------
+      // The reference scans the new neighbours in adjacency order, accepting j iff top_size < ef || lowerBound > d_j
+      // with the result set updated after every acceptance.  Equivalent closed form: with T the result set before
+      // this tile, j is accepted iff  #{t in T : t <= d_j} + #{i < j : d_i <= d_j}  <  ef  (every earlier neighbour
+      // that is not farther is itself accepted whenever j is, and evicted entries only ever lie beyond the ef-th
+      // rank).  Accepted entries then merge into the sorted set in one pass: an old entry moves up by the number of
+      // accepted keys strictly below it, an accepted one lands at #{T <= d} + #{accepted before it in (d, j) order}.
+      // Same set, same lowerBound sequence as far as any decision can see, a third of the vector instructions.
+      const bool cand_ok = (uint32_t)lane < cnt && (top_size < ef || lb > my_d);
+      const unsigned long long pm = hs_ballot(cand_ok);
+      if (pm) {
+        uint32_t A = 0, B = 0;
+        for (unsigned long long m = pm; m; m &= m - 1) {
+          const int j = __ffsll((long long)m) - 1;
+          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
+          uint32_t a = 0;
+#pragma unroll
+          for (int s = 0; s < S; s++) a += __popcll(hs_ballot((uint32_t)(lane + 64 * s) < top_size && tk[s] <= dj));
+          A = write_lane(A, a, j);
+          B += (cand_ok && lane > j && dj <= my_d) ? 1u : 0u;
+        }
+        const bool acc = cand_ok && (A + B < ef);
+        const unsigned long long am = hs_ballot(acc);
+        const uint32_t n_acc = __popcll(am);
+        uint32_t Bp = 0, shift[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) shift[s] = 0;
+        for (unsigned long long m = am; m; m &= m - 1) {
+          const int j = __ffsll((long long)m) - 1;
+          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
+          Bp += (acc && (dj < my_d || (dj == my_d && j < lane))) ? 1u : 0u;
+#pragma unroll
+          for (int s = 0; s < S; s++) shift[s] += tk[s] > dj ? 1u : 0u;
+        }
+        uint2 *stage = reinterpret_cast<uint2 *>(smem + L.off_stage);
+        const uint32_t old_size = top_size;
+        float dropped = FLT_MAX;   // smallest key pushed beyond the capacity (only needed when ef == k)
+        if (watch_boundary || want_drop) {
+          if (acc && A + Bp >= ef) dropped = my_d;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const uint32_t r = lane + 64 * s;
+            if (r < top_size && r + shift[s] >= ef) dropped = fminf(dropped, tk[s]);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint32_t r = lane + 64 * s, nr = r + shift[s];
+          if (r < top_size && nr < ef) stage[nr] = make_uint2(__float_as_uint(tk[s]), ti[s]);
+        }
+        if (acc && A + Bp < ef) stage[A + Bp] = make_uint2(__float_as_uint(my_d), my_id);
+        wave_sync();
+        top_size = min(top_size + n_acc, ef);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint32_t r = lane + 64 * s;
+          if (r < top_size) {
+            const uint2 e = stage[r];
+            tk[s] = __uint_as_float(e.x);
+            ti[s] = e.y;
+          }
+        }
+        wave_sync();
+        lb = top_key_at<S>(tk, top_size - 1);  // :450-452
+        if ((watch_boundary || want_drop) && old_size + n_acc > ef) drop_tie = hs_ballot(dropped == lb) != 0;   // (dropped keys are >= lb: the smallest equals it iff one does)
+        if (watch_boundary) boundary_tie = boundary_tie || drop_tie;
+        pending = am;
+        last_acc = n_acc;
+        if (am) {
+          if (__builtin_expect(tlog != nullptr, 1) && acc) {
+            const uint32_t at = n_log + __popcll(am & ((1ull << lane) - 1ull));
+            if (at < a.log_cap) tlog[at] = make_uint2(__float_as_uint(my_d), my_id);
+          }
+          n_log += n_acc;
+        }
+      }
+  };
+
   // ---- level-0 beam (hnswalg_slim.h:321-457) -----------------------------------------------------
   // The reference pushes accepted neighbours into candidate_set one by one and pops its root at the top of the next
   // iteration.  Which entry that root will be does not need the accept pass at all: a pushed entry only rises past
@@ -713,7 +811,134 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
   // Neither HBM round trip of an expansion waits for heap work and the heap work waits for neither.
   uint32_t id = kNone;   // adjacency tile of the node to expand: one aligned, coalesced read from its id
   if (rc == 0 && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
-  while (rc == 0) {
+
+  // ---- the same beam without the heap, until a tie (see FLAT above) ---------------------------------------------------
+  constexpr uint32_t kDone = 0x80000000u;   // bit 31 of a result-set id: that entry has been expanded
+  uint8_t *hoplog = (FLAT && a.spill && a.hop_cap) ? reinterpret_cast<uint8_t *>(a.spill + (size_t)qi * a.spill_stride + a.spill_slots + 2 * a.cand2_cap + 2 * a.log_cap) : nullptr;
+  bool flat = FLAT && a.flat != 0 && hoplog != nullptr && tlog != nullptr && ix.n < kDone && rc == 0;
+  bool flat_done = false;     // the search ended on the flat path
+  if (FLAT && flat) {
+    uint32_t hops_flat = 0;
+    if (lane == 0) ti[0] |= kDone;   // the entry is the one element of the set and the node being expanded
+    while (true) {
+      if (__builtin_expect(next_d > lb, 0)) { flat_done = true; break; }   // :340 (next is the nearest unexpanded entry)
+      c.n_hops++;
+      const bool valid = id != kNone;
+      const uint32_t m = __popcll(hs_ballot(valid));
+      bool isnew = false;
+      if (vis.qbits) {
+        bool fail = false;
+        isnew = vis_test_and_mark_q16(vis, id, valid, a, lane, fail);  // :392-393
+        if (__builtin_expect(fail, 0)) { rc = 1; break; }
+      } else {
+        if (__builtin_expect(!vis_reserve(vis, m, a, lane), 0)) { rc = 1; break; }
+        if (valid) isnew = vis_insert(vis, id);  // :392-393
+      }
+      const unsigned long long nm = hs_ballot(isnew);
+      const uint32_t cnt = __popcll(nm);
+      c.n_nbr += m;
+      wave_sync();
+      if (isnew) nid[__popcll(nm & ((1ull << lane) - 1ull))] = id;  // unvisited ids, adjacency order
+      wave_sync();
+      if (!vis.qbits) vis_commit(vis, cnt);
+      c.n_dist += cnt;
+      if (__builtin_expect(cnt > 0, 1)) wave_dists<METRIC, D16>(ix, qv, nid, nd, cnt, lane);  // :395-396
+      wave_sync();
+      const float my_d = (uint32_t)lane < cnt ? nd[lane] : FLT_MAX;
+      const uint32_t my_id = (uint32_t)lane < cnt ? nid[lane] : 0;
+      // nearest unexpanded entry of the set as it stands (the old "root"), against the nearest new neighbour
+      bool have_next = false;
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        const unsigned long long um = hs_ballot((uint32_t)(lane + 64 * s) < top_size && ti[s] < kDone);
+        if (!have_next && um) {
+          const int p = __ffsll((long long)um) - 1;
+          next_d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tk[s]), p));
+          next_id = __builtin_amdgcn_readlane(ti[s], p);
+          have_next = true;
+        }
+      }
+      const float best_d = wave_min_f32(my_d);
+      const bool have_best = cnt > 0 && (top_size < ef || lb > best_d);
+      if (have_best && (!have_next || best_d < next_d)) {
+        const int bl = __ffsll((long long)hs_ballot((uint32_t)lane < cnt && my_d == best_d)) - 1;
+        next_d = best_d;
+        next_id = __builtin_amdgcn_readlane(my_id, bl);
+        have_next = true;
+      }
+      id = kNone;
+      if (have_next && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
+      pending = 0;
+      accept_bare(my_d, my_id, cnt, true);   // pending = the accepted lanes
+      prev_d = my_d;
+      prev_id = my_id;
+      if (__builtin_expect(hops_flat >= a.hop_cap || n_log > a.log_cap, 0)) { rc = 3; break; }   // cannot be replayed: strict pass
+      if (lane == 0) hoplog[hops_flat] = (uint8_t)last_acc;
+      hops_flat++;
+      if (!have_next) { flat_done = true; break; }
+      // the chosen node among the unexpanded entries of the set as it is now: alone at its distance?
+      uint32_t same = 0;
+#pragma unroll
+      for (int s = 0; s < S; s++) same += __popcll(hs_ballot((uint32_t)(lane + 64 * s) < top_size && ti[s] < kDone && tk[s] == next_d));
+      if (__builtin_expect(drop_tie || same > 1, 0)) {
+        // ---- materialise candidate_set as the reference has it now: entry pushed; per expansion: pop, then that expansion's
+        //      accepted entries pushed -- all but the last expansion's, which are still pending (prev_d / prev_id / pending)
+        __threadfence_block();
+        cand_size = 0;
+        uint32_t idx = 0, base = 0;
+        uint2 e = make_uint2(0, 0);
+        uint32_t hl = 0;
+        for (uint32_t h = 0; h <= hops_flat; h++) {
+          // pushes of "expansion h-1" (h == 0: the entry), then the pop of expansion h
+          const uint32_t np = h == 0 ? 1u : (uint32_t)((__builtin_amdgcn_readlane(hl, (h - 1) & 63)));
+          if (h == hops_flat) break;   // (the last expansion's accepted entries stay pending)
+          if (__builtin_expect(cand_size + np > cand_total, 0)) { rc = 2; break; }
+          for (uint32_t q = 0; q < np; q++) {
+            if ((idx & 63u) == 0) { base = idx; e = (base + lane < n_log) ? tlog[base + lane] : make_uint2(0, 0); }
+            const uint32_t dx = __builtin_amdgcn_readlane(e.x, idx & 63u), ix_ = __builtin_amdgcn_readlane(e.y, idx & 63u);
+            cand_size++;
+            cand_push(cand, cand_size, __uint_as_float(dx), ix_, lane);
+            wave_sync();
+            idx++;
+          }
+          if ((h & 63u) == 0) hl = (h + lane < hops_flat) ? (uint32_t)hoplog[h + lane] : 0u;
+          if (lane == 0) cand_pop(cand, cand_size);
+          cand_size--;
+          wave_sync();
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) ti[s] &= ~kDone;
+        // the node the heap path expands next: nearest pending entry if strictly nearer than the heap's root, else the root
+        const float pd = (pending >> lane) & 1ull ? my_d : FLT_MAX;
+        const float pbest = wave_min_f32(pd);
+        bool hn = pending != 0;
+        if (cand_size > 0) {
+          const uint2 root = cand.lds[1];
+          next_d = unif(__uint_as_float(root.x));
+          next_id = uni(root.y);
+          hn = true;
+        }
+        if (pending != 0 && (cand_size == 0 || pbest < next_d)) {
+          const int bl = __ffsll((long long)hs_ballot(((pending >> lane) & 1ull) && my_d == pbest)) - 1;
+          next_d = pbest;
+          next_id = __builtin_amdgcn_readlane(my_id, bl);
+        }
+        id = kNone;
+        if (hn && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
+        if (lane == 0) atomicAdd(a.queue + 1, 1u);   // diagnostic: queries that left the flat path
+        break;
+      }
+      // flag the chosen node expanded where it sits in the set
+#pragma unroll
+      for (int s = 0; s < S; s++)
+        if ((uint32_t)(lane + 64 * s) < top_size && ti[s] == next_id) ti[s] |= kDone;
+    }
+    if (flat_done || rc != 0) {
+#pragma unroll
+      for (int s = 0; s < S; s++) ti[s] &= ~kDone;
+    }
+  }
+  while (rc == 0 && !flat_done) {
     if (__builtin_expect(cand_size == 0 && pending == 0, 0)) break;
     if (__builtin_expect(bare ? (next_d > lb) : (next_d > lb && top_size == ef), 0)) break;  // :340 / :346-347
     c.n_hops++;
@@ -784,80 +1009,7 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
       if (have_next && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
     }
     if (__builtin_expect(bare, 1)) {
-      // ---- accept decisions (:403-452) for the whole tile at once --------------------------------------------
-      // The reference scans the new neighbours in adjacency order, accepting j iff top_size < ef || lowerBound > d_j
-      // with the result set updated after every acceptance.  Equivalent closed form: with T the result set before
-      // this tile, j is accepted iff  #{t in T : t <= d_j} + #{i < j : d_i <= d_j}  <  ef  (every earlier neighbour
-      // that is not farther is itself accepted whenever j is, and evicted entries only ever lie beyond the ef-th
-      // rank).  Accepted entries then merge into the sorted set in one pass: an old entry moves up by the number of
-      // accepted keys strictly below it, an accepted one lands at #{T <= d} + #{accepted before it in (d, j) order}.
-      // Same set, same lowerBound sequence as far as any decision can see, a third of the vector instructions.
-      const bool cand_ok = (uint32_t)lane < cnt && (top_size < ef || lb > my_d);
-      const unsigned long long pm = hs_ballot(cand_ok);
-      if (pm) {
-        uint32_t A = 0, B = 0;
-        for (unsigned long long m = pm; m; m &= m - 1) {
-          const int j = __ffsll((long long)m) - 1;
-          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
-          uint32_t a = 0;
-#pragma unroll
-          for (int s = 0; s < S; s++) a += __popcll(hs_ballot((uint32_t)(lane + 64 * s) < top_size && tk[s] <= dj));
-          A = write_lane(A, a, j);
-          B += (cand_ok && lane > j && dj <= my_d) ? 1u : 0u;
-        }
-        const bool acc = cand_ok && (A + B < ef);
-        const unsigned long long am = hs_ballot(acc);
-        const uint32_t n_acc = __popcll(am);
-        uint32_t Bp = 0, shift[S];
-#pragma unroll
-        for (int s = 0; s < S; s++) shift[s] = 0;
-        for (unsigned long long m = am; m; m &= m - 1) {
-          const int j = __ffsll((long long)m) - 1;
-          const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_d), j));
-          Bp += (acc && (dj < my_d || (dj == my_d && j < lane))) ? 1u : 0u;
-#pragma unroll
-          for (int s = 0; s < S; s++) shift[s] += tk[s] > dj ? 1u : 0u;
-        }
-        uint2 *stage = reinterpret_cast<uint2 *>(smem + L.off_stage);
-        const uint32_t old_size = top_size;
-        float dropped = FLT_MAX;   // smallest key pushed beyond the capacity (only needed when ef == k)
-        if (watch_boundary) {
-          if (acc && A + Bp >= ef) dropped = my_d;
-#pragma unroll
-          for (int s = 0; s < S; s++) {
-            const uint32_t r = lane + 64 * s;
-            if (r < top_size && r + shift[s] >= ef) dropped = fminf(dropped, tk[s]);
-          }
-        }
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-          const uint32_t r = lane + 64 * s, nr = r + shift[s];
-          if (r < top_size && nr < ef) stage[nr] = make_uint2(__float_as_uint(tk[s]), ti[s]);
-        }
-        if (acc && A + Bp < ef) stage[A + Bp] = make_uint2(__float_as_uint(my_d), my_id);
-        wave_sync();
-        top_size = min(top_size + n_acc, ef);
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-          const uint32_t r = lane + 64 * s;
-          if (r < top_size) {
-            const uint2 e = stage[r];
-            tk[s] = __uint_as_float(e.x);
-            ti[s] = e.y;
-          }
-        }
-        wave_sync();
-        lb = top_key_at<S>(tk, top_size - 1);  // :450-452
-        if (watch_boundary && old_size + n_acc > ef) boundary_tie = boundary_tie || wave_min_f32(dropped) == lb;
-        pending = am;
-        if (am) {
-          if (__builtin_expect(tlog != nullptr, 1) && acc) {
-            const uint32_t at = n_log + __popcll(am & ((1ull << lane) - 1ull));
-            if (at < a.log_cap) tlog[at] = make_uint2(__float_as_uint(my_d), my_id);
-          }
-          n_log += n_acc;
-        }
-      }
+      accept_bare(my_d, my_id, cnt, false);
     } else {
     // accept decisions (:403-452) in adjacency order.  Once the result set is full lowerBound only
     // decreases, so entries that fail against the current bound can never pass later: skip them wholesale.
@@ -1016,7 +1168,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(fast_wa
       if (threadIdx.x == 0) { if (a.out_counts) a.out_counts[qi] = 0; a.status[qi] = ST_DONE; }
       continue;
     }
-    const int rc = search_one_fast<METRIC, S, D16, WB, BARE>(ix, a, qi, smem);
+    const int rc = search_one_fast<METRIC, S, D16, WB, BARE, BARE && !WB>(ix, a, qi, smem);
     if (rc == 3 && threadIdx.x == 0) a.status[qi] = ST_HAZARD;
     wave_sync();
   }

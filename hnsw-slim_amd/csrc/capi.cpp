@@ -145,7 +145,8 @@ static constexpr uint32_t kLeanMinEf = 192;   // from here upwards the lean kern
 static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
 static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
 static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)
-static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap + 2 * kLogCap;  // words per query
+static constexpr uint32_t kHopCap = 4096;      // 4 KiB per query: accepted neighbours per expansion (flat start of the fast kernel)
+static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap + 2 * kLogCap + kHopCap / 4;  // words per query
 
 static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
@@ -689,6 +690,9 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
   a.status = w->status.p;
   a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
+  a.hop_cap = kHopCap;
+  static const bool flat_off = getenv("HS_FLAT") && atoi(getenv("HS_FLAT")) == 0;   // diagnostic: heap path from the first expansion
+  a.flat = flat_off ? 0u : 1u;
   // A launch that cannot fill the GPU anyway (fewer queries than wavefront slots) lasts as long as its longest query, and
   // LDS is not what limits it: the 16-bit visited set then takes up to 4x the buckets, as far as the queries of this launch
   // still all fit on the chip at once -- the longest queries never see a full bucket.

@@ -36,7 +36,7 @@ struct SearchArgs {
   uint32_t hash_slots;   // visited-set tier-1 (LDS) slots
   uint32_t *spill;       // per-query tier-2 region in global memory (nullable): [spill_slots u32 visited-set
                          // slots][cand2_cap x 8 B candidate-heap slots], spill_stride words apart
-  uint32_t spill_slots, spill_stride, cand2_cap, log_cap;  // then log_cap x 8 B: result-set insertion log
+  uint32_t spill_slots, spill_stride, cand2_cap, log_cap;  // then log_cap x 8 B: result-set insertion log, then hop_cap bytes
   int32_t mode;          // hs_mode
   int32_t mark_ep;       // tag the enter point visited before the descent (slim (q,k) overloads)
   uint32_t select_mask;  // process query qi iff (1 << status[qi]) & select_mask
@@ -54,6 +54,8 @@ struct SearchArgs {
   uint32_t pass_id;
   uint32_t *queue;       // group kernel: device-wide query counter (zeroed per launch group)
   uint32_t hash_fill_shift;   // visited-set tier 1 is frozen at 1 - 2^-shift of its slots (0 = the default 2: 75 %)
+  uint32_t flat;         // fast kernel: start the level-0 search without the candidate heap (beam_search.hip, FLAT)
+  uint32_t hop_cap;      // bytes of the per-expansion accept counts behind the insertion log (one per expansion of the flat start)
   uint32_t vis_bits;     // fast kernel: 0 = visited-set tier 1 in 32-bit slots; else the width of the id space for the
                          // 16-bit form (search_common.hpp; hash_slots / 4 buckets, a power of two, vis_bits - log2(buckets) <= 16)
   // Fast kernel in two launches (see launch_order): phase 1 stops after the upper-level descent and leaves
