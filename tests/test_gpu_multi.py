@@ -188,7 +188,9 @@ np.savez(sys.argv[3], **out)
     for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "0"}), ("group", {"HS_GROUP": "1"}), ("lean", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "0"}),
                      ("fast_ordered", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "1"}), ("lean_ordered", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "1"}),
                      # the visited set's 32-bit form (what an index beyond 2^(log2(buckets)+16) nodes gets) instead of the 16-bit one
-                     ("fast_vis32", {"HS_LEAN_MIN_EF": "100000", "HS_VIS16": "0"}), ("lean_vis32", {"HS_LEAN_MIN_EF": "1", "HS_VIS16": "0"})):
+                     ("fast_vis32", {"HS_LEAN_MIN_EF": "100000", "HS_VIS16": "0"}), ("lean_vis32", {"HS_LEAN_MIN_EF": "1", "HS_VIS16": "0"}),
+                     # the candidate heap from the first expansion instead of the flat start + materialisation on a tie
+                     ("fast_heap", {"HS_LEAN_MIN_EF": "100000", "HS_FLAT": "0"})):
         of = str(tmp_path / f"{tag}.npz")
         subprocess.check_call([sys.executable, wf, ROOT, str(tmp_path), of], env=dict(os.environ, **env))
         res[tag] = np.load(of)
@@ -199,6 +201,7 @@ np.savez(sys.argv[3], **out)
         assert np.array_equal(res["fast"][key], res["lean_ordered"][key]), key
         assert np.array_equal(res["fast"][key], res["fast_vis32"][key]), key
         assert np.array_equal(res["fast"][key], res["lean_vis32"][key]), key
+        assert np.array_equal(res["fast"][key], res["fast_heap"][key]), key
 
 
 def test_index_from_host_arrays_equals_index_from_file(hs, slim_file):

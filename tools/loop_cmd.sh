@@ -1,8 +1,13 @@
-# development A/B: flat start of the fast kernel (default) against the heap path from the first expansion (HS_FLAT=0)
+# same-box A/B of the judged bench: flat start (default) against HS_FLAT=0
 cd $GRAFT_REPO_ROOT
-timeout -k 10 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 || exit 1
+timeout -k 10 300 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -2 || exit 1
 python tools/qbench.py --efs 70 > /dev/null 2>&1
-for NQ in 1250 10000 65536; do
-  echo "nq=$NQ heap"; HS_FLAT=0 python tools/qbench.py --efs 32,70,128 --nq $NQ --reps 5 2>&1 | grep -E "^ef="
-  echo "nq=$NQ flat"; HS_VERBOSE=1 python tools/qbench.py --efs 32,70,128 --nq $NQ --reps 5 --check 2>&1 | grep -E "^ef=|equal False"
-done
+run() {
+  python bench.py --index-dir /tmp/idx --ef 70 --no-cpu-baseline > gpurun_out/ab_$1.json 2> gpurun_out/ab_$1.log
+  python - "$1" <<PY
+import json, sys
+j=json.loads(open(f"gpurun_out/ab_{sys.argv[1]}.json").read().strip().split("\n")[-1]); c=j["config"]; r=j["roofline"]
+print(sys.argv[1], "value",j["value"],"frac",r["frac"],"launch_ms",r["launch_ms"],"timed",r["timed_region_frac"],"devres",c["device_resident_pipelined_qps"])
+PY
+}
+for rep in 1 2; do HS_FLAT=0 run heap; run flat; done
