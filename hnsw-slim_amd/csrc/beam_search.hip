@@ -925,7 +925,6 @@ __device__ int search_one_fast(const DevIndex &ix, const SearchArgs &a, const ui
         }
         id = kNone;
         if (hn && (uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
-        if (lane == 0) atomicAdd(a.queue + 1, 1u);   // diagnostic: queries that left the flat path
         break;
       }
       // flag the chosen node expanded where it sits in the set

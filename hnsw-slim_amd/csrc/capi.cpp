@@ -848,8 +848,8 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   // later batches start with twice the visited-set slots / candidate capacity.
   const size_t nq = std::max<size_t>(w->last_nq, 1);
   static const bool verbose = getenv("HS_VERBOSE") != nullptr;
-  if (verbose) fprintf(stderr, "[hs check] nq %zu: visited overflow %u, candidate overflow %u, tie replays %u, visited-set spills %u, left the flat path %u | pass 2: %u %u | grow_hash %u grow_cand %u\n",
-                       nq, c[0], c[1], c[2], c[3], c[13], c[8], c[9], ix->grow_hash, ix->grow_cand);
+  if (verbose) fprintf(stderr, "[hs check] nq %zu: visited overflow %u, candidate overflow %u, tie replays %u, visited-set spills %u | pass 2: %u %u | grow_hash %u grow_cand %u\n",
+                       nq, c[0], c[1], c[2], c[3], c[8], c[9], ix->grow_hash, ix->grow_cand);
   if ((size_t)c[3] * 10 > nq && ix->grow_hash < 8 && !ix->user_hash_slots) ix->grow_hash++;
   if ((size_t)(c[1] + c[5]) * 100 > nq && ix->grow_cand < 4 && !ix->user_cand_cap) ix->grow_cand++;
   if (ix->info.kind == HS_KIND_SLIMQ) {
