@@ -354,6 +354,8 @@ def main():
             if os.path.exists(tpath) and N == 1_000_000 and NQ == 10_000 and D == 128 and chosen == json.load(open(tpath)).get("ef"):
                 traffic, tsrc = json.load(open(tpath))["hbm_bytes_per_launch"], "profiles/" + name
                 break
+        # which search kernel serves this shape (csrc/capi.cpp: the lean kernel from ef = 64 on L2 d = 96 / 128, else the fast kernel)
+        kname = "hs::lean_kernel" if (chosen >= 64 and D in (96, 128)) else "hs::fast_kernel"
         step_ms = elapsed / args.steps * 1e3
         batch_ms = elapsed / n_batches * 1e3
         achieved_single = alg_bytes_launch / (kern_ms * 1e-3) / 1e9   # one launch alone on the GPU
@@ -378,9 +380,9 @@ def main():
             # timed_region_*: the same bytes / the effective per-batch time of the timed region (S batches in flight, PCIe included).
             "roofline": {"bound": "hbm", "achieved": round(achieved_single, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_single / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": "hs::fast_kernel", "launch_ms": round(kern_ms, 4),
-                         "launch": "one 10k-query pass = fast_kernel (upper-level descent) + order_kernel (start order) + fast_kernel "
-                                   "(level-0 search); launch_ms spans the three, a rocprofv3 kernel trace shows two fast_kernel "
+                         "kernel": kname, "launch_ms": round(kern_ms, 4),
+                         "launch": f"one 10k-query pass = {kname[4:]} (upper-level descent) + order_kernel (start order) + {kname[4:]} "
+                                   f"(level-0 search); launch_ms spans the three, a rocprofv3 kernel trace shows two {kname[4:]} "
                                    "dispatches per pass whose durations add up to it (profiles/r02_kernel_stats_1stream.csv)",
                          "timed_region_achieved": round(eff, 1), "timed_region_frac": round(eff / HBM_PEAK_GBS, 4),
                          "launches_in_flight": S, "algorithmic_bytes_per_launch": alg_bytes_launch},

@@ -140,8 +140,9 @@ struct Shape {
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
-static constexpr uint32_t kLeanMinEf = 192;   // from here upwards the lean kernel (keys-only result set, smaller LDS share) is the faster one:
-                                              // +11 % single launch / +15 % steady state at ef=256, -7 % / +5 % at 128, slower below (profiles/r02_lean_kernel_experiment.log)
+static constexpr uint32_t kLeanMinEf = 64;    // from here upwards the lean kernel (keys-only result set, 95 VGPRs: 5 waves per SIMD without scratch, smaller LDS share)
+                                              // is the faster one on its shapes (L2, d = 96 / 128): ef=70 -5 % single launch / +4 % on a 32k call (0.41 of the HBM peak),
+                                              // ef=128 -13 % / +13 %, ef=160 -25 % / +34 %; at ef=48 the fast kernel with the flat start still wins (profiles/r02_ordered_pass_experiments.log)
 static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
 static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
 static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)

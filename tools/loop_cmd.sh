@@ -1,7 +1,6 @@
-# same-box A/B of the judged bench: flat start (default) against HS_FLAT=0
+# same-box A/B of the judged bench: lean kernel from ef=64 (default) against the fast kernel (HS_LEAN_MIN_EF=100000)
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -2 || exit 1
-python tools/qbench.py --efs 70 > /dev/null 2>&1
+timeout -k 10 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 || exit 1
 run() {
   python bench.py --index-dir /tmp/idx --ef 70 --no-cpu-baseline > gpurun_out/ab_$1.json 2> gpurun_out/ab_$1.log
   python - "$1" <<PY
@@ -10,4 +9,4 @@ j=json.loads(open(f"gpurun_out/ab_{sys.argv[1]}.json").read().strip().split("\n"
 print(sys.argv[1], "value",j["value"],"frac",r["frac"],"launch_ms",r["launch_ms"],"timed",r["timed_region_frac"],"devres",c["device_resident_pipelined_qps"])
 PY
 }
-for rep in 1 2; do HS_FLAT=0 run heap; run flat; done
+for rep in 1 2; do HS_LEAN_MIN_EF=100000 run fast; run lean; done

@@ -25,7 +25,7 @@ def per_launch(path, kernel_sub, counters):
 
 # A 10k-query pass of the fast kernel is two dispatches since round 2 (descent, then level-0 search in entry-distance order,
 # csrc/capi.cpp search_dev_group): "per launch" figures are per PASS, i.e. the per-dispatch average times two.
-DISPATCHES_PER_PASS = {"fast_kernel": 2} if (len(sys.argv) > 1 and sys.argv[1] != "r01") else {}
+DISPATCHES_PER_PASS = {"fast_kernel": 2, "lean_kernel": 2} if (len(sys.argv) > 1 and sys.argv[1] != "r01") else {}
 
 
 for s in ("1stream", "pipelined"):
@@ -35,9 +35,10 @@ for s in ("1stream", "pipelined"):
     open(os.path.join(DST, f"{tag}_kernel_stats_{s}.csv"), "w").writelines(rows)
 b = json.load(open(os.path.join(SRC, "bench_1stream.json")))
 ef = b["config"]["ef_search"]
-fetch, _ = per_launch(newest("pmc_FETCH_SIZE/**/*counter_collection.csv"), "fast_kernel", ["FETCH_SIZE"])
-write, _ = per_launch(newest("pmc_WRITE_SIZE/**/*counter_collection.csv"), "fast_kernel", ["WRITE_SIZE"])
-tcc, _ = per_launch(newest("pmc_TCC_HIT_sum/**/*counter_collection.csv"), "fast_kernel", ["TCC_HIT_sum", "TCC_MISS_sum"])
+KERNEL = b["roofline"].get("kernel", "hs::fast_kernel").split("::")[-1]   # the search kernel that served the bench shape
+fetch, _ = per_launch(newest("pmc_FETCH_SIZE/**/*counter_collection.csv"), KERNEL, ["FETCH_SIZE"])
+write, _ = per_launch(newest("pmc_WRITE_SIZE/**/*counter_collection.csv"), KERNEL, ["WRITE_SIZE"])
+tcc, _ = per_launch(newest("pmc_TCC_HIT_sum/**/*counter_collection.csv"), KERNEL, ["TCC_HIT_sum", "TCC_MISS_sum"])
 cal, ncal = per_launch(newest("pmc_calib/**/*counter_collection.csv"), "gather", ["FETCH_SIZE"])
 known = 1 << 30
 corr = known / (cal["FETCH_SIZE"] * 1024)
@@ -45,7 +46,7 @@ hbm = fetch["FETCH_SIZE"] * 1024 * corr + write["WRITE_SIZE"] * 1024
 out = {
     "workload": f"SIFT-1M-like d=128 N=1000000 nq=10000 ef={ef} k=10, 1 stream",
     "ef": ef,
-    "kernel": "hs::fast_kernel<0,2,8>" + (" (both dispatches of a pass: descent + level-0 search)" if DISPATCHES_PER_PASS else ""),
+    "kernel": "hs::" + KERNEL + (" (both dispatches of a pass: descent + level-0 search)" if DISPATCHES_PER_PASS else ""),
     "FETCH_SIZE_KiB_per_launch": round(fetch["FETCH_SIZE"], 1),
     "WRITE_SIZE_KiB_per_launch": round(write["WRITE_SIZE"], 1),
     "calibration": {
@@ -75,10 +76,10 @@ for d, title in (("pmc_insts", "instruction mix"), ("pmc_wait", "where a wavefro
     f = newest(f"{d}/**/*counter_collection.csv")
     if not f:
         continue
-    tot, nd = totals(f, "fast_kernel")
-    passes = max(nd // DISPATCHES_PER_PASS.get("fast_kernel", 1), 1)
+    tot, nd = totals(f, KERNEL)
+    passes = max(nd // DISPATCHES_PER_PASS.get(KERNEL, 1), 1)
     lines.append(f"{title}: rocprofv3 --pmc {' '.join(sorted(tot))} -- python bench.py --ef {ef} --streams 1 --steps 2 --warmup 1 "
-                 f"(hs::fast_kernel, {nd} dispatches = {passes} passes of 10000 queries; per-pass averages; SQ_WAVE_CYCLES and the wait/active counters count quad-cycles)")
+                 f"(hs::{KERNEL}, {nd} dispatches = {passes} passes of 10000 queries; per-pass averages; SQ_WAVE_CYCLES and the wait/active counters count quad-cycles)")
     for k in sorted(tot):
         lines.append(f"    {k:22s} {tot[k] / passes:16.0f}")
     if "SQ_INSTS_VALU" in tot:
