@@ -60,8 +60,8 @@ def recall_at_k(labels, gt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--base-size", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--batch", dest="nq", type=int, default=10_000)

@@ -81,6 +81,7 @@ struct hs_index {
   bool exact_order = false;               // always use the strict kernel (reference output order)
   // patching (hs_index_patch): a Slim index loaded with max_elements > count keeps its host image and has row capacity
   std::unique_ptr<SlimGraph> host_slim;
+  bool integer_data = false;   // every sampled vector component is an integer (set at upload; steers the kernel choice)
   size_t cap_rows = 0;
   DevIndex dev{};
   DevBuf<float> vec;
@@ -140,6 +141,7 @@ struct Shape {
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
+static constexpr uint32_t kLeanMinEfContinuous = 192;   // continuous data: the fast kernel's flat start never materialises a heap and wins below this
 static constexpr uint32_t kLeanMinEf = 64;    // from here upwards the lean kernel (keys-only result set, 95 VGPRs: 5 waves per SIMD without scratch, smaller LDS share)
                                               // is the faster one on its shapes (L2, d = 96 / 128): ef=70 -5 % single launch / +4 % on a 32k call (0.41 of the HBM peak),
                                               // ef=128 -13 % / +13 %, ef=160 -25 % / +34 %; at ef=48 the fast kernel with the flat start still wins (profiles/r02_ordered_pass_experiments.log)
@@ -307,6 +309,20 @@ static hs_status upload_small(hs_index *ix, const PackedIndex &p) {
 
 static hs_status upload(hs_index *ix, const PackedIndex &p) {
   HIP_TRY(hipSetDevice(ix->device));
+  // Integer-valued vectors (SIFT-like) give integer distances, i.e. candidates that tie: the flat start of the fast kernel
+  // then falls back to the heap in a quarter of the queries and the lean kernel is the faster one from ef = 64; on
+  // continuous data the flat start never leaves its path and wins up to ef = 128 (DEEP-10M: 8.8 vs 7.9 M q/s at ef=64).
+  // A strided sample of the rows decides which regime this index is in (kernel choice only: every kernel is exact on both).
+  {
+    bool integral = p.n > 0 && p.vec.size() >= p.n * p.dim;   // (a SlimQ index carries no fp32 rows here)
+    const size_t step = std::max<size_t>(p.n / 4096, 1);
+    for (size_t i = 0; i < p.n && integral; i += step)
+      for (size_t j = 0; j < p.dim; j++) {
+        const float v = p.vec[i * p.dim + j];
+        if (!(v == std::floor(v)) || std::fabs(v) > 16777216.f) { integral = false; break; }
+      }
+    ix->integer_data = integral;
+  }
   const size_t cap = std::max(ix->cap_rows, p.n);
   HIP_TRY(upload_cap(ix->vec, p.vec, cap * p.dim));
   // level-0 adjacency tiles: node i's ids padded with 0xFFFFFFFF to a fixed, 64-byte-multiple stride
@@ -728,7 +744,8 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   // The lean kernel answers from HS_LEAN_MIN_EF upwards (diagnostic knob; default: see kLeanMinEf)
   static const uint32_t lean_min_ef = getenv("HS_LEAN_MIN_EF") ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
   static const bool lean_forced = getenv("HS_LEAN_MIN_EF") != nullptr;   // the parity tests force it on every shape it supports
-  const bool lean = !group && fast && sh.ef >= lean_min_ef && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
+  const uint32_t lean_from = lean_forced ? lean_min_ef : (ix->integer_data ? kLeanMinEf : kLeanMinEfContinuous);
+  const bool lean = !group && fast && sh.ef >= lean_from && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
                     lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots) <= kLdsPerCU;
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
