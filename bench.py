@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cand-cap", type=int, default=0)
     ap.add_argument("--hash-slots", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=8, help="HIP streams the batches are issued on round-robin (batches in flight); 1 = strictly serial")
+    ap.add_argument("--streams", type=int, default=16, help="HIP streams the batches are issued on round-robin (batches in flight); 1 = strictly serial")
     ap.add_argument("--batches-per-step", type=int, default=10)
     ap.add_argument("--query-sets", type=int, default=8, help="distinct pre-generated query batches rotated through")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
