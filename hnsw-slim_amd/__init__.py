@@ -77,6 +77,7 @@ def lib():
     L.hs_search_batch.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp]
     L.hs_search_batch_dev.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_search_check.argtypes = [vp, vp]
+    L.hs_debug_heap_ops.argtypes = [vp, sz, ci, u32, vp, vp, vp]
     L.hs_search_batch_async.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_host_alloc.restype = vp
     L.hs_host_alloc.argtypes = [sz]
@@ -147,6 +148,20 @@ def convert_slim_gpu(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_le
                                      top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, device, threads, out_path.encode(),
                                      ctypes.byref(used), ctypes.byref(ms)))
     return bool(used.value), ms.value
+
+
+def debug_heap_ops(ops, wave_pop=True, lds_slots=1024):
+    """hs_debug_heap_ops: ops = [(0, dist, id) | (1, 0, 0), ...] -> (heap [(dist, id)], pops [(dist, id)]) from the device."""
+    n = len(ops)
+    arr = np.zeros((max(n, 1), 3), np.uint32)
+    for i, (kind, d, idv) in enumerate(ops):
+        arr[i] = (kind, np.float32(d).view(np.uint32), idv)
+    heap = np.zeros((n + 2, 2), np.uint32)
+    pops = np.zeros((n + 2, 2), np.uint32)
+    cnt = np.zeros(2, np.uint32)
+    _check(lib().hs_debug_heap_ops(arr.ctypes.data, n, 1 if wave_pop else 0, lds_slots, heap.ctypes.data, pops.ctypes.data, cnt.ctypes.data))
+    f = lambda a, m: [(float(a[i, 0:1].view(np.float32)[0]), int(a[i, 1])) for i in range(m)]
+    return f(heap, int(cnt[0])), f(pops, int(cnt[1]))
 
 
 def brute_force(base, queries, k, metric=HS_METRIC_L2, labels=None, device=0):

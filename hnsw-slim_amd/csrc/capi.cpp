@@ -54,9 +54,11 @@ struct DevBuf {
   size_t n = 0;
   hipError_t alloc(size_t count) {
     release();
-    n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void **)&p, count * sizeof(T));
+    const hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;   // (a failed allocation leaves the buffer empty: the next ensure() tries again)
+    else p = nullptr;
+    return e;
   }
   hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
   hipError_t upload(const std::vector<T> &v) {
@@ -149,7 +151,8 @@ static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 vis
 static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
 static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)
 static constexpr uint32_t kHopCap = 4096;      // 4 KiB per query: accepted neighbours per expansion (flat start of the fast kernel)
-static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap + 2 * kLogCap + kHopCap / 4;  // words per query
+static constexpr uint32_t kParkWords = 2048;   // 8 KiB per query: where the flat kernel parks the head of its visited set during a heap replay
+static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap + 2 * kLogCap + kHopCap / 4 + kParkWords;  // words per query
 
 static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
@@ -234,6 +237,41 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   s.fb_cand_cap = (uint32_t)((cand_bytes / 8) & ~size_t(1));
   if (s.fb_cand_cap < s.cand_cap) { s.fb_cand_cap = s.cand_cap; s.fb_hash_slots = s.hash_slots; }
   return HS_OK;
+}
+
+// Flat kernel (flat_search.hip): visited-set buckets, the division constants of bucket = h mod nb, and the LDS share of its
+// (lazily replayed) candidate heap.  The bucket count takes whatever LDS the wave's residency granule leaves unused: a launch
+// that fills the chip runs 5 wavefronts per SIMD = 20 workgroups per CU = 8 KiB each, a smaller launch fewer and larger ones.
+struct FlatPlan { uint32_t nb, mul, sh, vis_bits; bool ok; };
+static FlatPlan plan_flat(const hs_index *ix, uint32_t ef, size_t nq) {
+  FlatPlan f{};
+  const uint32_t dim = (uint32_t)ix->info.dim;
+  uint32_t idbits = 1;
+  while (idbits < 32 && ((uint64_t)1 << idbits) < (uint64_t)std::max<size_t>(ix->info.n, 2)) idbits++;
+  f.vis_bits = idbits;
+  // expected visited ids per query (distance evaluations, measured on the 1M SIFT-like bench index: 450 + 5 ef), 3.2 per bucket of 7
+  uint32_t nb = ix->user_hash_slots ? std::max<uint32_t>(ix->user_hash_slots / 4, 8) : (uint32_t)((450 + 5.0 * ef) * (1.0 + 0.25 * ix->grow_hash) / 3.2);
+  nb = std::max<uint32_t>(nb, 8);
+  if (!ix->user_hash_slots) {
+    const size_t total = flatk_lds_bytes(dim, ef, nb);
+    size_t waves = std::min<size_t>(20, kLdsPerCU / std::max<size_t>(total, 1));
+    waves = std::min(waves, std::max<size_t>((nq + 255) / 256, 1));   // a launch smaller than the wave slots: fewer, larger shares
+    if (waves >= 1) {
+      const size_t share = std::min<size_t>((kLdsPerCU / waves) & ~size_t(15), 64 * 1024);
+      if (share > total) nb += (uint32_t)((share - total) / 16);
+    }
+  }
+  nb = std::min<uint32_t>(nb, 1u << 14);
+  // remainders h div nb must fit 15 bits
+  while (((uint64_t)1 << idbits) / nb > 32767 && nb < (1u << 16)) nb += nb / 2;
+  if (((uint64_t)1 << idbits) / nb > 32767 || idbits > 31) return f;
+  uint32_t sh = 0;
+  while ((2u << sh) <= nb) sh++;   // floor(log2(nb))
+  uint64_t m = (((uint64_t)1 << (32 + sh)) + nb - 1) / nb;
+  if (m >> 32) { sh--; m = (((uint64_t)1 << (32 + sh)) + nb - 1) / nb; }
+  f.nb = nb; f.mul = (uint32_t)m; f.sh = sh;
+  f.ok = flatk_lds_bytes(dim, ef, nb) <= kLdsPerCU;
+  return f;
 }
 
 template <typename T>
@@ -692,13 +730,17 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   hs_index::StreamWs *w = ix->stream_ws(stream);
   HIP_TRY(w->status.ensure(nq));
   HIP_TRY(w->spill.ensure(nq * (size_t)kSpillStride));
-  HIP_TRY(w->counters.ensure(48));
   // (status needs no clearing: pass 0 takes every query and writes each one's final status)
-  // counters[0..12): per-pass overflow / hazard counts (accumulate over the launch groups of one call); [12]: the group
-  // kernel's query queue head (per launch group)
-  if (first_group) HIP_TRY(hipMemsetAsync(w->counters.p, 0, 48 * sizeof(uint32_t), stream));
-  else HIP_TRY(hipMemsetAsync(w->counters.p + 12, 0, sizeof(uint32_t), stream));
-  w->last_nq = nq_total;
+  // counters[0..12): per-pass overflow / hazard counts.  They are STICKY: they accumulate over the launch groups of a call and
+  // over every call issued on this stream until hs_search_check reads and clears them, so a capacity failure in any batch of
+  // a pipelined sequence is reported by the check that follows it.  [12]: the group kernel's query queue head (per launch group)
+  if (w->counters.n < 48) {
+    HIP_TRY(w->counters.ensure(48));
+    HIP_TRY(hipMemsetAsync(w->counters.p, 0, 48 * sizeof(uint32_t), stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(w->counters.p + 12, 0, sizeof(uint32_t), stream));
+  }
+  if (first_group) w->last_nq += nq_total;   // queries since the last hs_search_check on this stream
   SearchArgs a{};
   a.queries = d_q; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.ef = sh.ef;
   a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.mode = mode;
@@ -747,11 +789,35 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   const uint32_t lean_from = lean_forced ? lean_min_ef : (ix->integer_data ? kLeanMinEf : kLeanMinEfContinuous);
   const bool lean = !group && fast && sh.ef >= lean_from && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
                     lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots) <= kLdsPerCU;
+  // The flat kernel (lazy candidate heap, flat_search.hip) answers every bare index it supports; HS_KERNEL=lean|fast selects the
+  // older kernels for A/B runs and for their parity tests, HS_KERNEL=flat forces it.
+  static const char *kernel_env = getenv("HS_KERNEL");
+  static const bool flatk_off = kernel_env && (!strcmp(kernel_env, "lean") || !strcmp(kernel_env, "fast"));
+  const FlatPlan fp = plan_flat(ix, sh.ef, nq);
+  const bool flatk = !flatk_off && !group && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
   static const int order_env = getenv("HS_ORDER") ? atoi(getenv("HS_ORDER")) : -1;   // diagnostic: 0 = never, 1 = always
   const bool ordered = fast && !group && (order_env < 0 ? nq >= kOrderMinQueries : order_env != 0);
-  if (lean) {
+  if (flatk) {
+    // pass 0: the flat kernel; a query that exhausts its scratch is left ST_OVERFLOW, one whose logs did not fit ST_HAZARD
+    a.hash_slots = fp.nb * 4; a.vis_bits = fp.vis_bits; a.fl_nb = fp.nb; a.fl_mul = fp.mul; a.fl_sh = fp.sh;
+    a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
+    if (ordered) {   // descent / order / level-0 search, as for the fast kernel below
+      HIP_TRY(w->entry.ensure(nq * 4));
+      HIP_TRY(w->order.ensure(nq));
+      a.entry = reinterpret_cast<uint4 *>(w->entry.p); a.order = w->order.p;
+      a.phase = 1;
+      HIP_TRY(launch_flatk(ix->dev, a, stream));
+      HIP_TRY(launch_order(a.entry, w->order.p, (uint32_t)nq, stream));
+      a.phase = 2;
+      HIP_TRY(launch_flatk(ix->dev, a, stream));
+      a.phase = 0;
+    } else {
+      HIP_TRY(launch_flatk(ix->dev, a, stream));
+    }
+    a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.vis_bits = 0;
+  } else if (lean) {
     // pass 0: the lean kernel; a query that exhausts even its tier-2 regions is left ST_OVERFLOW for the passes below
     a.cand_cap = sh.l_cand_cap; a.hash_slots = sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots; a.hash_fill_shift = 3; a.vis_bits = sh.q_bits;
     a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
@@ -810,7 +876,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   // the whole-CU pass exists: a batch is then two kernel launches, not three.
   const bool big_pass = sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots;
   // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
-  if ((fast || group || lean) && !big_pass) {
+  if ((fast || group || lean || flatk) && !big_pass) {
     a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
     a.counters = w->counters.p + 4; a.pass_id = 1;
     HIP_TRY(launch_strict(ix->dev, a, stream));
@@ -819,7 +885,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   if (big_pass) {
     // few workgroups: each needs a whole CU's LDS, i.e. a CU drained of every other wave before it can start -- with
     // several batches in flight a wide grid of them stalls the stream even when (as usual) no query is flagged
-    a.select_mask = (1u << ST_OVERFLOW) | ((fast || group || lean) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, 16);
+    a.select_mask = (1u << ST_OVERFLOW) | ((fast || group || lean || flatk) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, 16);
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
     a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));
@@ -850,6 +916,7 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   hs_index::StreamWs *w = ix->stream_ws((hipStream_t)stream);
   if (!w->counters.p) return HS_OK;  // nothing was launched on this stream
   HIP_TRY(hipMemcpyAsync(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(c), (hipStream_t)stream));   // read and cleared: see search_dev_group
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   if (getenv("HS_GPROF") && w->counters.n >= 48) {   // diagnostic build (make gprof): per-phase shader clocks of the group kernel
     unsigned long long g[16];
@@ -865,6 +932,7 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   // learn the scratch sizes from the data: if more than 1% of a batch overflowed in the first passes,
   // later batches start with twice the visited-set slots / candidate capacity.
   const size_t nq = std::max<size_t>(w->last_nq, 1);
+  w->last_nq = 0;
   static const bool verbose = getenv("HS_VERBOSE") != nullptr;
   if (verbose) fprintf(stderr, "[hs check] nq %zu: visited overflow %u, candidate overflow %u, tie replays %u, visited-set spills %u | pass 2: %u %u | grow_hash %u grow_cand %u\n",
                        nq, c[0], c[1], c[2], c[3], c[8], c[9], ix->grow_hash, ix->grow_cand);
@@ -876,6 +944,26 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   }
   if (c[8] + c[9] > 0)
     return fail(HS_ERR_CAPACITY, std::to_string(c[8] + c[9]) + " queries exhausted even a whole CU's on-chip scratch");
+  return HS_OK;
+}
+
+hs_status hs_debug_heap_ops(const uint32_t *ops, size_t n_ops, int wave_pop, uint32_t lds_slots, uint32_t *out_heap, uint32_t *out_pops,
+                            uint32_t *out_n) {
+  if (!ops || !out_heap || !out_pops || !out_n) return fail(HS_ERR_INVALID, "null argument");
+  if (lds_slots < 2 || lds_slots > 8192 || (lds_slots & 1)) return fail(HS_ERR_INVALID, "lds_slots: even, 2..8192");
+  DevBuf<uint32_t> d_ops, d_n;
+  DevBuf<uint2> d_spill, d_heap, d_pops;
+  HIP_TRY(d_ops.alloc(std::max<size_t>(3 * n_ops, 1)));
+  HIP_TRY(d_n.alloc(2));
+  HIP_TRY(d_spill.alloc(n_ops + 2));
+  HIP_TRY(d_heap.alloc(n_ops + 2));
+  HIP_TRY(d_pops.alloc(n_ops + 2));
+  HIP_TRY(hipMemcpy(d_ops.p, ops, 3 * n_ops * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(flat_heap_ops(d_ops.p, (uint32_t)n_ops, d_spill.p, d_heap.p, d_pops.p, d_n.p, wave_pop, lds_slots, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_n, d_n.p, 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_heap, d_heap.p, (size_t)out_n[0] * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_pops, d_pops.p, (size_t)out_n[1] * 8, hipMemcpyDeviceToHost));
   return HS_OK;
 }
 
@@ -1023,9 +1111,11 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   HIP_TRY(hipSetDevice(ix->device));
   hs_index::StreamWs *w = ix->stream_ws(stream);
   HIP_TRY(w->status.ensure(nq));
-  HIP_TRY(w->counters.ensure(12));
-  HIP_TRY(hipMemsetAsync(w->counters.p, 0, 12 * sizeof(uint32_t), stream));   // status: written for every query by the first pass
-  w->last_nq = nq;
+  if (w->counters.n < 48) {   // sticky until hs_search_check clears them (see search_dev_group); status: written for every query by the first pass
+    HIP_TRY(w->counters.ensure(48));
+    HIP_TRY(hipMemsetAsync(w->counters.p, 0, 48 * sizeof(uint32_t), stream));
+  }
+  w->last_nq += nq;
   SlimQArgs a{};
   a.queries = d_queries; a.nq = (uint32_t)nq; a.k = (uint32_t)k; a.pool_cap = (uint32_t)ix->ef;
   // expansions per query stay below ~ef on real graphs; 75 % fill of 4 ef slots leaves 3x headroom, and a query

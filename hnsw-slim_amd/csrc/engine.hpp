@@ -64,6 +64,9 @@ struct SearchArgs {
   uint32_t phase;
   uint4 *entry;
   const uint32_t *order;
+  // Flat kernel (flat_search.hip): visited set of fl_nb 16-byte buckets; bucket = h mod fl_nb, remainder = h div fl_nb =
+  // umulhi(h, fl_mul) >> fl_sh (exact for h < 2^vis_bits; remainders fit 15 bits)
+  uint32_t fl_nb, fl_mul, fl_sh;
 };
 
 // Bytes of dynamic LDS one query (one wavefront) needs.
@@ -85,6 +88,12 @@ bool lean_preferred(const DevIndex &ix);   // shapes on which it beats the fast 
 size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
 hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 // Group kernel (group_search.hip): four queries per wavefront, persistent grid; same contract as the fast kernel.
+// Flat kernel (flat_search.hip): lazy candidate heap -- replayed from the insertion log only when its layout decides a pop.
+bool flatk_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
+size_t flatk_lds_bytes(uint32_t dim, uint32_t ef, uint32_t nb);
+hipError_t launch_flatk(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
+hipError_t flat_heap_ops(const uint32_t *d_ops, uint32_t n_ops, uint2 *d_spill, uint2 *d_heap, uint2 *d_pops, uint32_t *d_n, int wave_pop,
+                         uint32_t lds_slots, hipStream_t stream);
 bool group_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 bool group_q_in_regs(int metric, uint32_t dim);
 size_t group_lds_bytes(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots, bool q_in_regs);

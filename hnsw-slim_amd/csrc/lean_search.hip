@@ -501,6 +501,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_LEAN
 template <typename K>
 static hipError_t lean_launch(K kern, const DevIndex &ix, const SearchArgs &a, size_t lds, hipStream_t stream) {
   if (a.nq == 0) return hipSuccess;
+  if (lds > 64 * 1024) {   // (a large user cand_cap, or the candidate share after hs_search_check doubled it)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(kern, dim3(std::max(1u, std::min(a.grid, a.nq))), dim3(64), lds, stream, ix, a);
   return hipGetLastError();
 }

@@ -137,6 +137,12 @@ hs_status hs_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, s
                               uint32_t *d_out_labels32, uint64_t *d_out_labels64, float *d_out_dists,
                               uint32_t *d_out_counts, uint32_t *d_stats, void *stream);
 hs_status hs_search_check(hs_index *ix, void *stream);
+/* Parity/debug entry: a sequence of candidate_set operations (std::push_heap / std::pop_heap with compare_by_first_rev,
+ * hnswalg_slim.h:177-183, 331-332, 353-354, 408-411) through the flat kernel's heap code on the device.  ops: 3 words each
+ * {0 = push | 1 = pop, distance bits, id}; wave_pop selects the whole-wave pop; lds_slots: heap slots kept in LDS (the rest
+ * in global memory).  out_heap / out_pops: 2 words per entry (n_ops entries of room each); out_n: {final size, pops}. */
+hs_status hs_debug_heap_ops(const uint32_t *ops, size_t n_ops, int wave_pop, uint32_t lds_slots, uint32_t *out_heap, uint32_t *out_pops,
+                            uint32_t *out_n);
 
 /* Host pointers, asynchronous: H2D of the queries, the search and D2H of the requested outputs are enqueued on `stream`
  * and nothing is valid until that stream is synchronised (hs_search_check does it and reports capacity problems).  The
