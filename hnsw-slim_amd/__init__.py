@@ -72,6 +72,8 @@ def lib():
     L.hs_index_free.restype = None
     L.hs_set_ef.argtypes = [vp, sz]
     L.hs_index_info.argtypes = [vp, ctypes.POINTER(HsInfo)]
+    L.hs_last_kernel.argtypes = [vp]
+    L.hs_last_kernel.restype = ctypes.c_char_p
     L.hs_set_capacity.argtypes = [vp, u32, u32]
     L.hs_set_exact_order.argtypes = [vp, ci]
     L.hs_search_batch.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp]
@@ -476,6 +478,9 @@ class Index:
         _check(lib().hs_slimq_search_batch_dev(self._h, d_queries.data_ptr(), d_queries.shape[0], k, d_labels.data_ptr(),
                                                d_dists.data_ptr(), d_counts.data_ptr(),
                                                d_stats.data_ptr() if d_stats is not None else None, stream))
+
+    def last_kernel(self):
+        return lib().hs_last_kernel(self._h).decode()
 
     def check(self, stream=0):
         _check(lib().hs_search_check(self._h, stream))

@@ -81,6 +81,7 @@ struct hs_index {
   uint32_t user_cand_cap = 0, user_hash_slots = 0;
   uint32_t grow_cand = 0, grow_hash = 0;  // adaptive: doublings learnt from earlier batches' overflow counts
   bool exact_order = false;               // always use the strict kernel (reference output order)
+  const char *last_kernel = "";           // the kernel that served pass 0 of the most recent search call (hs_last_kernel)
   // patching (hs_index_patch): a Slim index loaded with max_elements > count keeps its host image and has row capacity
   std::unique_ptr<SlimGraph> host_slim;
   bool integer_data = false;   // every sampled vector component is an integer (set at upload; steers the kernel choice)
@@ -254,7 +255,8 @@ static FlatPlan plan_flat(const hs_index *ix, uint32_t ef, size_t nq) {
   nb = std::max<uint32_t>(nb, 8);
   if (!ix->user_hash_slots) {
     const size_t total = flatk_lds_bytes(dim, ef, nb);
-    size_t waves = std::min<size_t>(20, kLdsPerCU / std::max<size_t>(total, 1));
+    static const size_t max_waves = getenv("HS_FLAT_WAVES_PER_CU") ? (size_t)atoi(getenv("HS_FLAT_WAVES_PER_CU")) : 20;   // diagnostic: builds with another residency
+    size_t waves = std::min<size_t>(max_waves, kLdsPerCU / std::max<size_t>(total, 1));
     waves = std::min(waves, std::max<size_t>((nq + 255) / 256, 1));   // a launch smaller than the wave slots: fewer, larger shares
     if (waves >= 1) {
       const size_t share = std::min<size_t>((kLdsPerCU / waves) & ~size_t(15), 64 * 1024);
@@ -700,6 +702,7 @@ hs_status hs_set_exact_order(hs_index *ix, int on) {
   ix->exact_order = on != 0;
   return HS_OK;
 }
+const char *hs_last_kernel(const hs_index *ix) { return ix ? ix->last_kernel : ""; }
 hs_status hs_index_info(const hs_index *ix, hs_info *out) {
   if (!ix || !out) return fail(HS_ERR_INVALID, "null argument");
   *out = ix->info;
@@ -795,6 +798,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   static const bool flatk_off = kernel_env && (!strcmp(kernel_env, "lean") || !strcmp(kernel_env, "fast"));
   const FlatPlan fp = plan_flat(ix, sh.ef, nq);
   const bool flatk = !flatk_off && !group && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);
+  ix->last_kernel = flatk ? "hs::flat_kernel" : lean ? "hs::lean_kernel" : group ? "hs::group_kernel" : fast ? "hs::fast_kernel" : "hs::strict_kernel";
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
   static const int order_env = getenv("HS_ORDER") ? atoi(getenv("HS_ORDER")) : -1;   // diagnostic: 0 = never, 1 = always
@@ -1127,6 +1131,7 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   a.trace = ix->trace_ptr; a.trace_cap = ix->trace_cap;
   const uint32_t pw = slimq_prep_words(ix->sq.ncl, ix->sq.padded);
   HIP_TRY(w->prep.ensure(nq * (size_t)pw));
+  ix->last_kernel = "hs::slimq_kernel";
   HIP_TRY(launch_slimq_prep(ix->sq, (uint32_t)ix->info.dim, ix->info.metric, d_queries, (uint32_t)nq, w->prep.p, nullptr, stream));
   a.prep = w->prep.p;
   a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq; a.counters = w->counters.p;

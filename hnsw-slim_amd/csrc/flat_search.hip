@@ -165,57 +165,63 @@ struct FlatHeap {
 };
 typedef uint32_t hs_u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) hs_u2 lds_u64;
+// T2 = false: every slot touched is known to lie in LDS -> straight-line LDS code (no address tests, no global access)
+template <bool T2>
 __device__ __forceinline__ uint2 fh_get(const FlatHeap &h, uint32_t s) {
-  if (s < h.L) { const hs_u2 v = *reinterpret_cast<lds_u64 *>(h.lds + s * 8); return make_uint2(v.x, v.y); }
+  if (!T2 || s < h.L) { const hs_u2 v = *reinterpret_cast<lds_u64 *>(h.lds + s * 8); return make_uint2(v.x, v.y); }
   return h.glob[s];
 }
+template <bool T2>
 __device__ __forceinline__ void fh_set(const FlatHeap &h, uint32_t s, uint2 v) {
-  if (s < h.L) *reinterpret_cast<lds_u64 *>(h.lds + s * 8) = hs_u2{v.x, v.y};
+  if (!T2 || s < h.L) *reinterpret_cast<lds_u64 *>(h.lds + s * 8) = hs_u2{v.x, v.y};
   else h.glob[s] = v;
 }
+template <bool T2>
 __device__ __forceinline__ uint4 fh_get2(const FlatHeap &h, uint32_t s /*even*/) {
-  if (s < h.L) { const hs_u4 v = *reinterpret_cast<lds_u128 *>(h.lds + s * 8); return make_uint4(v.x, v.y, v.z, v.w); }
+  if (!T2 || s < h.L) { const hs_u4 v = *reinterpret_cast<lds_u128 *>(h.lds + s * 8); return make_uint4(v.x, v.y, v.z, v.w); }
   return *reinterpret_cast<const uint4 *>(&h.glob[s]);
 }
 // std::push_heap: all ancestors of the new slot are known up front, so the whole wave does it in one read and one write round
+template <bool T2>
 __device__ __forceinline__ void fh_push(const FlatHeap &h, uint32_t n /*size incl. new*/, float d, uint32_t id, int lane) {
   const uint32_t anc = n >> (lane + 1);
   const bool has = anc != 0 && lane < 31;
   uint2 p = make_uint2(0, 0);
-  if (has) p = fh_get(h, anc);
+  if (has) p = fh_get<T2>(h, anc);
   const unsigned long long rises = hs_ballot(has && __uint_as_float(p.x) > d);
   const uint32_t r = __ffsll((long long)~rises) - 1;
-  if ((uint32_t)lane < r) fh_set(h, n >> lane, p);
-  if ((uint32_t)lane == r) fh_set(h, n >> r, make_uint2(__float_as_uint(d), id));
+  if ((uint32_t)lane < r) fh_set<T2>(h, n >> lane, p);
+  if ((uint32_t)lane == r) fh_set<T2>(h, n >> r, make_uint2(__float_as_uint(d), id));
 }
 // std::pop_heap (one lane); the popped root was read by the caller beforehand
+template <bool T2>
 __device__ __forceinline__ void fh_pop(const FlatHeap &h, uint32_t n /*size before pop*/) {
   if (n <= 1) return;
-  const uint2 v = fh_get(h, n);
+  const uint2 v = fh_get<T2>(h, n);
   const uint32_t len = n - 1;
   uint32_t hole = 0, child = 0;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    const uint4 two = fh_get2(h, child);
+    const uint4 two = fh_get2<T2>(h, child);
     const bool left = __uint_as_float(two.z) > __uint_as_float(two.x);
-    fh_set(h, hole + 1, left ? make_uint2(two.x, two.y) : make_uint2(two.z, two.w));
+    fh_set<T2>(h, hole + 1, left ? make_uint2(two.x, two.y) : make_uint2(two.z, two.w));
     child = left ? child - 1 : child;
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    fh_set(h, hole + 1, fh_get(h, child));
+    fh_set<T2>(h, hole + 1, fh_get<T2>(h, child));
     hole = child - 1;
   }
   const float vd = __uint_as_float(v.x);
   while (hole > 0) {
     const uint32_t parent = (hole - 1) >> 1;
-    const uint2 p = fh_get(h, parent + 1);
+    const uint2 p = fh_get<T2>(h, parent + 1);
     if (!(__uint_as_float(p.x) > vd)) break;
-    fh_set(h, hole + 1, p);
+    fh_set<T2>(h, hole + 1, p);
     hole = parent;
   }
-  fh_set(h, hole + 1, v);
+  fh_set<T2>(h, hole + 1, v);
 }
 
 // std::pop_heap by the whole wave, for a heap that lies in LDS: __adjust_heap's walk to the bottom picks, at every node, one of
@@ -224,7 +230,7 @@ __device__ __forceinline__ void fh_pop(const FlatHeap &h, uint32_t n /*size befo
 // of 200 entries is popped in three LDS round trips instead of eight dependent ones.  Same decisions as fh_pop / std::pop_heap.
 __device__ __forceinline__ void fh_pop_wave(const FlatHeap &h, uint32_t n /*size before pop*/, int lane) {
   if (n <= 1) return;
-  const uint2 v = fh_get(h, n);   // a[n-1] (uniform address: broadcast)
+  const uint2 v = fh_get<false>(h, n);   // a[n-1] (uniform address: broadcast)
   const uint32_t len = n - 1;
   uint32_t hole = 0;
   const uint32_t dl = lane < 1 ? 0u : (lane < 3 ? 1u : 2u);   // depth of this lane's node below the hole
@@ -233,7 +239,7 @@ __device__ __forceinline__ void fh_pop_wave(const FlatHeap &h, uint32_t n /*size
     const uint32_t node = ((hole + 1u) << dl) - 1u + ol;
     const bool two = lane < 7 && 2u * node + 2u < len;   // the node has both children
     uint4 pr = make_uint4(0, 0, 0, 0);
-    if (two) pr = fh_get2(h, 2u * node + 2u);   // a[2 node + 1], a[2 node + 2]
+    if (two) pr = fh_get2<false>(h, 2u * node + 2u);   // a[2 node + 1], a[2 node + 2]
     const bool right = !(__uint_as_float(pr.z) > __uint_as_float(pr.x));   // comp(a[child], a[child-1]) false: take a[child]
     const unsigned long long vm = hs_ballot(two), rm = hs_ballot(two && right);
     uint32_t l = 0, path = 0, last = 0;
@@ -246,17 +252,133 @@ __device__ __forceinline__ void fh_pop_wave(const FlatHeap &h, uint32_t n /*size
     }
     if (path == 0) break;
     const uint32_t child = 2u * node + 1u + (right ? 1u : 0u);
-    if (lane < 7 && ((path >> lane) & 1u)) fh_set(h, node + 1u, right ? make_uint2(pr.z, pr.w) : make_uint2(pr.x, pr.y));
+    if (lane < 7 && ((path >> lane) & 1u)) fh_set<false>(h, node + 1u, right ? make_uint2(pr.z, pr.w) : make_uint2(pr.x, pr.y));
     hole = __builtin_amdgcn_readlane(child, last);
     if (!open) break;
   }
   if ((len & 1u) == 0 && hole == (len - 2u) / 2u) {   // a last node with a left child only
-    const uint2 c = fh_get(h, 2u * hole + 2u);
-    if (lane == 0) fh_set(h, hole + 1u, c);
+    const uint2 c = fh_get<false>(h, 2u * hole + 2u);
+    if (lane == 0) fh_set<false>(h, hole + 1u, c);
     hole = 2u * hole + 1u;
   }
   wave_sync();
-  fh_push(h, hole + 1u, __uint_as_float(v.x), v.y, lane);   // __push_heap(first, hole, top = 0, value)
+  fh_push<false>(h, hole + 1u, __uint_as_float(v.x), v.y, lane);   // __push_heap(first, hole, top = 0, value)
+}
+
+// The lazy candidate heap brought up to date and its root popped (see the file header): state = the reference's candidate_set
+// after `hp` pops and the pushes of `hq` hops; it rests in the query's scratch region in global memory (slot i + 1 = element i),
+// and for the replay the head of the visited-set area (up to 8 KiB) is parked in the scratch region and the heap's first slots
+// work in LDS.
+struct FlatSync {
+  lds_u8 *vis;
+  uint32_t *scratch;
+  uint32_t heap_lds_slots, off_heap, off_log, off_hop, hop_cap, cand_total;
+  uint32_t n_log, hop0, hl, lb_bits;
+  uint32_t cand_size, hp, hq, h_idx;
+};
+struct FlatSyncOut { uint32_t cand_size, hp, hq, h_idx, rc, stop, next_id; };
+#ifdef HS_FLAT_SYNC_CALL   // A/B knob (make flatvar): a real call costs the kernel a stack in scratch memory; measured slower
+#define HS_FLAT_SYNC_ATTR __attribute__((noinline))
+#else
+#define HS_FLAT_SYNC_ATTR __forceinline__
+#endif
+template <int METRIC>
+__device__ HS_FLAT_SYNC_ATTR FlatSyncOut flat_heap_sync(FlatSync f) {
+  const int lane = threadIdx.x;
+  // (arguments of a device function arrive in vector registers: everything that is the same in all lanes goes back to scalar ones,
+  //  so that the loops below are scalar loops)
+  lds_u8 *vis = (lds_u8 *)(uintptr_t)uni((uint32_t)(uintptr_t)f.vis);
+  const uint64_t sbits = (uint64_t)(uintptr_t)f.scratch;
+  uint32_t *scratch = reinterpret_cast<uint32_t *>((uintptr_t)(((uint64_t)uni((uint32_t)(sbits >> 32)) << 32) | uni((uint32_t)sbits)));
+  uint2 *heap_store = reinterpret_cast<uint2 *>(scratch + uni(f.off_heap));
+  const uint2 *tlog = reinterpret_cast<const uint2 *>(scratch + uni(f.off_log));
+  const uint32_t *hoplog = scratch + uni(f.off_hop);
+  hs_u4 *park = reinterpret_cast<hs_u4 *>(scratch + uni(f.off_hop) + uni(f.hop_cap));
+  const uint32_t heap_lds_slots = uni(f.heap_lds_slots), n_log = uni(f.n_log), hop0 = uni(f.hop0), hl = f.hl, cand_total = uni(f.cand_total);
+  const int lb = (int)uni(f.lb_bits);
+  uint32_t cand_size = uni(f.cand_size), hp = uni(f.hp), hq = uni(f.hq), h_idx = uni(f.h_idx), rc = 0, next_id = 0;
+  __threadfence_block();
+  for (uint32_t i = lane; i * 2u < heap_lds_slots; i += 64) park[i] = *reinterpret_cast<lds_u128 *>(vis + i * 16);
+  FlatHeap cand;
+  cand.lds = vis;
+  cand.L = heap_lds_slots;
+  cand.glob = heap_store;
+  wave_sync();
+  for (uint32_t sl = lane; sl <= cand_size && sl < heap_lds_slots; sl += 64) {
+    const uint2 e = heap_store[sl];
+    *reinterpret_cast<lds_u64 *>(vis + sl * 8) = hs_u2{e.x, e.y};
+  }
+  wave_sync();
+  uint32_t ebase = ~0u;
+  uint2 eb = make_uint2(0, 0);
+  auto log_at = [&](uint32_t i) -> uint2 {
+    if ((i & ~63u) != ebase) {
+      ebase = i & ~63u;
+      eb = (ebase + lane < n_log) ? tlog[ebase + lane] : make_uint2(0, 0);
+    }
+    return make_uint2(__builtin_amdgcn_readlane(eb.x, i & 63u), __builtin_amdgcn_readlane(eb.y, i & 63u));
+  };
+  if (h_idx == 0) {   // candidate_set = {entry} (hnswalg_slim.h:327-332)
+    const uint2 e = log_at(0);
+    cand_size = 1;
+    fh_push<false>(cand, cand_size, __uint_as_float(e.x), e.y, lane);
+    wave_sync();
+    h_idx = 1;
+  }
+  const uint32_t ring_base = hop0 & ~63u;
+  uint32_t hbase = ~0u, hcnt = 0;   // per-hop counts, 64 at a time (the unflushed block is still in `hl`)
+  while (hq < hop0) {   // per past hop: pop (:353-354), then that hop's pushes (:408-411)
+    if (hp == hq) {
+      if (cand_size < heap_lds_slots) fh_pop_wave(cand, cand_size, lane);
+      else if (lane == 0) fh_pop<true>(cand, cand_size);
+      cand_size--;
+      hp++;
+      wave_sync();
+    }
+    if ((hq & ~63u) != hbase) {
+      hbase = hq & ~63u;
+      hcnt = hbase == ring_base ? hl : hoplog[hbase + lane];
+    }
+    const uint32_t np = (uint32_t)__builtin_amdgcn_readlane(hcnt, hq & 63u);
+    if (__builtin_expect(cand_size + np > cand_total, 0)) { rc = 2; break; }
+    const bool in_lds = cand_size + np < heap_lds_slots;
+    for (uint32_t q = 0; q < np; q++) {
+      const uint2 e = log_at(h_idx);
+      cand_size++;
+      if (in_lds) fh_push<false>(cand, cand_size, __uint_as_float(e.x), e.y, lane);
+      else fh_push<true>(cand, cand_size, __uint_as_float(e.x), e.y, lane);
+      wave_sync();
+      h_idx++;
+    }
+    hq++;
+  }
+  bool stop = rc != 0 || cand_size == 0;
+  if (!stop) {
+    const uint2 root = fh_get<false>(cand, 1);
+    const uint32_t rkey_bits = uni(root.x);
+    if (dkey<METRIC>(__uint_as_float(rkey_bits)) > lb) {   // :340
+      stop = true;
+    } else {
+      next_id = uni(root.y);
+      if (cand_size < heap_lds_slots) fh_pop_wave(cand, cand_size, lane);
+      else if (lane == 0) fh_pop<true>(cand, cand_size);
+      cand_size--;
+      hp++;
+      wave_sync();
+    }
+  }
+  // the heap goes back to its store, the visited set back to LDS
+  for (uint32_t sl = lane; sl <= cand_size && sl < heap_lds_slots; sl += 64) {
+    const hs_u2 e = *reinterpret_cast<lds_u64 *>(vis + sl * 8);
+    heap_store[sl] = make_uint2(e.x, e.y);
+  }
+  wave_sync();
+  __threadfence_block();
+  for (uint32_t i = lane; i * 2u < heap_lds_slots; i += 64) *reinterpret_cast<lds_u128 *>(vis + i * 16) = park[i];
+  wave_sync();
+  FlatSyncOut o;
+  o.cand_size = cand_size; o.hp = hp; o.hq = hq; o.h_idx = h_idx; o.rc = rc; o.stop = stop ? 1u : 0u; o.next_id = next_id;
+  return o;
 }
 
 template <int S>
@@ -301,7 +423,7 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
   uint32_t n_dist = 1, n_hops = 0, n_nbr = 0;
 #ifdef HS_FLAT_DIAG   // diagnostic build (make flatdiag): per-query wall clock and replay counts behind the stats block
   const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
-  uint32_t diag_syncs = 0, diag_replayed = 0;
+  uint32_t diag_syncs = 0, diag_replayed = 0, diag_sync_ticks = 0;
 #endif
 
   // ---- stage the query, clear the visited set ---------------------------------------------------------------------------
@@ -473,10 +595,6 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
   // lazy candidate heap (search_common.hpp): state = the reference's candidate_set after `hp` pops and the pushes of `hq` hops.
   // Between two replays it rests in the query's scratch region in global memory (slot i + 1 = element i, as CandHeap has it);
   // for a replay the first 8 KiB of the visited-set area are parked in the scratch region and the heap's first 1024 slots work in LDS.
-  uint2 *heap_store = reinterpret_cast<uint2 *>(scratch + a.spill_slots);
-  hs_u4 *park = reinterpret_cast<hs_u4 *>(hoplog + hop_cap);   // 8 KiB behind the hop counts
-  const uint32_t heap_lds_slots = min(a.fl_nb * 2u, 1024u) & ~1u;   // 8-byte slots of the swapped area (even)
-  const uint32_t cand_total = a.cand2_cap - 2;
   uint32_t cand_size = 0, hp = 0, hq = 0, h_idx = 0;
   const uint32_t stride = ix.tile_stride;
   int rc = vfail ? 1 : 0;
@@ -512,84 +630,25 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
       break;   // nothing left that the reference could pop with dist <= lowerBound
     }
     if (__builtin_expect(need_heap, 0)) {
-      // ---- bring the heap up to date: entry, then per past hop: pop, pushes (:353-354, 408-411) ------------------------
+      // ---- bring the heap up to date and pop its root (a real call: the replay keeps its own registers, see flat_heap_sync) ----
 #ifdef HS_FLAT_DIAG
       diag_syncs += any == 0 ? 0x10000u : (ghost_key == lb ? 0x100u : 1u);
       diag_replayed += hop0 - hq;
+      const unsigned long long diag_s0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      __threadfence_block();
-      for (uint32_t i = lane; i * 2u < heap_lds_slots; i += 64) park[i] = *reinterpret_cast<lds_u128 *>(vis + i * 16);
-      FlatHeap cand;
-      cand.lds = vis;
-      cand.L = heap_lds_slots;
-      cand.glob = heap_store;
-      wave_sync();
-      for (uint32_t sl = lane; sl <= cand_size && sl < heap_lds_slots; sl += 64) {
-        const uint2 e = heap_store[sl];
-        *reinterpret_cast<lds_u64 *>(vis + sl * 8) = hs_u2{e.x, e.y};
-      }
-      wave_sync();
-      uint32_t ebase = ~0u;
-      uint2 eb = make_uint2(0, 0);
-      auto log_at = [&](uint32_t i) -> uint2 {
-        if ((i & ~63u) != ebase) {
-          ebase = i & ~63u;
-          eb = (ebase + lane < n_log) ? tlog[ebase + lane] : make_uint2(0, 0);
-        }
-        return make_uint2(__builtin_amdgcn_readlane(eb.x, i & 63u), __builtin_amdgcn_readlane(eb.y, i & 63u));
-      };
-      if (h_idx == 0) {
-        const uint2 e = log_at(0);
-        cand_size = 1;
-        fh_push(cand, cand_size, __uint_as_float(e.x), e.y, lane);
-        wave_sync();
-        h_idx = 1;
-      }
-      const uint32_t ring_base = hop0 & ~63u;
-      while (hq < hop0) {
-        if (hp == hq) {
-          if (cand_size < heap_lds_slots) fh_pop_wave(cand, cand_size, lane);
-          else if (lane == 0) fh_pop(cand, cand_size);
-          cand_size--;
-          hp++;
-          wave_sync();
-        }
-        const uint32_t np = hq >= ring_base ? (uint32_t)__builtin_amdgcn_readlane(hl, hq & 63u) : uni(hoplog[hq]);
-        if (__builtin_expect(cand_size + np > cand_total, 0)) { rc = 2; break; }
-        for (uint32_t q = 0; q < np; q++) {
-          const uint2 e = log_at(h_idx);
-          cand_size++;
-          fh_push(cand, cand_size, __uint_as_float(e.x), e.y, lane);
-          wave_sync();
-          h_idx++;
-        }
-        hq++;
-      }
-      bool stop = rc != 0 || cand_size == 0;
-      if (!stop) {
-        const uint2 root = fh_get(cand, 1);
-        const uint32_t rkey_bits = uni(root.x);
-        if (dkey<METRIC>(__uint_as_float(rkey_bits)) > lb) {   // :340
-          stop = true;
-        } else {
-          next_id = uni(root.y);
-          if (cand_size < heap_lds_slots) fh_pop_wave(cand, cand_size, lane);
-          else if (lane == 0) fh_pop(cand, cand_size);
-          cand_size--;
-          hp++;
-          wave_sync();
-        }
-      }
-      // the heap goes back to its store, the visited set back to LDS
-      for (uint32_t sl = lane; sl <= cand_size && sl < heap_lds_slots; sl += 64) {
-        const hs_u2 e = *reinterpret_cast<lds_u64 *>(vis + sl * 8);
-        heap_store[sl] = make_uint2(e.x, e.y);
-      }
-      wave_sync();
-      __threadfence_block();
-      for (uint32_t i = lane; i * 2u < heap_lds_slots; i += 64) *reinterpret_cast<lds_u128 *>(vis + i * 16) = park[i];
-      wave_sync();
-      if (stop) break;
+      FlatSync fs;
+      fs.vis = vis; fs.heap_lds_slots = min(a.fl_nb * 2u, 1024u) & ~1u; fs.scratch = scratch; fs.off_heap = a.spill_slots;
+      fs.off_log = a.spill_slots + 2 * a.cand2_cap; fs.off_hop = fs.off_log + 2 * a.log_cap; fs.hop_cap = hop_cap;
+      fs.cand_total = a.cand2_cap - 2; fs.n_log = n_log; fs.hop0 = hop0; fs.hl = hl; fs.lb_bits = (uint32_t)lb;
+      fs.cand_size = cand_size; fs.hp = hp; fs.hq = hq; fs.h_idx = h_idx;
+      const FlatSyncOut fo = flat_heap_sync<METRIC>(fs);
+      cand_size = fo.cand_size; hp = fo.hp; hq = fo.hq; h_idx = fo.h_idx;
+#ifdef HS_FLAT_DIAG
+      diag_sync_ticks += (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_s0);
+#endif
+      if (fo.rc != 0) { rc = (int)fo.rc; break; }
+      if (fo.stop) break;
+      next_id = fo.next_id;
     }
     // flag the node expanded where it sits in the result set
 #pragma unroll
@@ -666,7 +725,7 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
         n_acc_hop += na;
       }
     }
-    hl = write_lane(hl, n_acc_hop, hop0 & 63u);
+    hl = write_lane(hl, uni(n_acc_hop), uni(hop0 & 63u));
     hop0++;
     if (__builtin_expect((hop0 & 63u) == 0, 0)) {
       if (hop0 > hop_cap) { rc = 3; break; }
@@ -745,7 +804,9 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
       a.stats[qi * 4 + 2] = n_nbr;
       a.stats[qi * 4 + 3] = replay ? 1u : a.pass_id;
 #ifdef HS_FLAT_DIAG
-      uint32_t *dg = a.stats + (size_t)a.nq * 4 + qi * 4;
+      uint32_t *dg = a.stats + (size_t)a.nq * 4 + qi * 8;
+      dg[4] = (uint32_t)diag_t0;                                          // start, 100 MHz ticks (low word)
+      dg[5] = diag_sync_ticks;                                            // ticks spent inside heap replays
       dg[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0);   // 100 MHz ticks
       dg[1] = diag_syncs;
       dg[2] = diag_replayed;
@@ -814,18 +875,19 @@ __global__ void __launch_bounds__(64) flat_heap_ops_kernel(const uint32_t *ops, 
     const uint32_t kind = uni(ops[3 * i]), key = uni(ops[3 * i + 1]), id = uni(ops[3 * i + 2]);
     if (kind == 0) {
       size++;
-      fh_push(h, size, __uint_as_float(key), id, lane);
+      if (size < h.L) fh_push<false>(h, size, __uint_as_float(key), id, lane);
+      else fh_push<true>(h, size, __uint_as_float(key), id, lane);
     } else if (size > 0) {
-      const uint2 root = fh_get(h, 1);
+      const uint2 root = fh_get<true>(h, 1);
       if (lane == 0) out_pops[pops] = root;
       pops++;
       if (wave_pop && size < h.L) fh_pop_wave(h, size, lane);
-      else if (lane == 0) fh_pop(h, size);
+      else if (lane == 0) { if (size < h.L) fh_pop<false>(h, size); else fh_pop<true>(h, size); }
       size--;
     }
     wave_sync();
   }
-  for (uint32_t s = lane; s < size; s += 64) out_heap[s] = fh_get(h, s + 1);
+  for (uint32_t s = lane; s < size; s += 64) out_heap[s] = fh_get<true>(h, s + 1);
   if (lane == 0) { out_n[0] = size; out_n[1] = pops; }
 }
 hipError_t flat_heap_ops(const uint32_t *d_ops, uint32_t n_ops, uint2 *d_spill, uint2 *d_heap, uint2 *d_pops, uint32_t *d_n, int wave_pop,

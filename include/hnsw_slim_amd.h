@@ -94,6 +94,9 @@ hs_status hs_index_patch(hs_index *ix, const void *bytes, size_t len, int to_add
 void hs_index_free(hs_index *ix);                        /* ~HierarchicalNSW* / clear(): hnswalg_slim.h:154-167 */
 hs_status hs_set_ef(hs_index *ix, size_t ef);            /* setEf: hnswalg.h:184, hnswalg_slim.h:193 */
 hs_status hs_index_info(const hs_index *ix, hs_info *out);
+/* Name of the device kernel that served pass 0 of the most recent search call on this index ("hs::flat_kernel", ...): the kernel
+ * a rocprofv3 kernel trace of that call shows; for measurement scripts, no counterpart in the reference. */
+const char *hs_last_kernel(const hs_index *ix);
 
 /* Output-order policy of the result set.  0 (default): the fast kernel answers, each query's entries
  * come out sorted by ascending distance; the k-subset (ids and distances) is exactly the reference's --

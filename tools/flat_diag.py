@@ -16,11 +16,18 @@ idir = sys.argv[1] if len(sys.argv) > 1 else "/tmp/hsidx"
 efs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [48, 68, 128]
 NQ, K, D = int(os.environ.get("NQ", "10000")), 10, 128
 dev = torch.device("cuda", 0)
+if not os.path.exists(os.path.join(idir, "slim.bin")):   # same files as bench.py --index-dir
+    os.makedirs(idir, exist_ok=True)
+    base = headline_data(int(os.environ.get("N", "1000000")), D, 123)
+    hs.build_hnsw(base, os.path.join(idir, "hnsw.bin"), M=16, ef_construction=200, branching_factor="4", seed=100, threads=min(len(os.sched_getaffinity(0)), 64))
+    hs.convert_slim(os.path.join(idir, "hnsw.bin"), os.path.join(idir, "slim.bin"), D, threads=min(len(os.sched_getaffinity(0)), 64))
+    np.save(os.path.join(idir, "base.npy"), base)
+    open(os.path.join(idir, "ready"), "w").write("ok")
 ix = hs.Index(os.path.join(idir, "slim.bin"), hs.HS_KIND_SLIM, D)
 q_t = torch.from_numpy(headline_data(NQ, D, 456)).to(dev)
 lab = torch.empty((NQ, K), dtype=torch.int32, device=dev)
 cnt = torch.empty((NQ,), dtype=torch.int32, device=dev)
-stats = torch.zeros((2 * NQ, 4), dtype=torch.int32, device=dev)
+stats = torch.zeros((3 * NQ, 4), dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for ef in efs:
     ix.set_ef(ef)
@@ -33,7 +40,7 @@ for ef in efs:
     e1.record()
     torch.cuda.synchronize()
     h = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    s4, dg = h[:NQ], h[NQ:]
+    s4, dg = h[:NQ], h[NQ:].reshape(NQ, 8)
     wall = dg[:, 0] / 100.0   # us
     hops, rep = s4[:, 1], dg[:, 2]
     c_tie, c_ghost, c_end = dg[:, 1] & 0xFF, (dg[:, 1] >> 8) & 0xFF, dg[:, 1] >> 16
@@ -46,5 +53,11 @@ for ef in efs:
           f"us/hop among them {wall[syncs > 0].sum() / max(hops[syncs > 0].sum(), 1):.2f}; other passes: {(s4[:, 3] > 1).sum()} replays-at-k: {(s4[:, 3] == 1).sum()}")
     print(f"   sync causes (queries with >= 1): tie among unexpanded entries {(c_tie > 0).mean() * 100:.1f}%, ghost at the bound mid-search {(c_ghost > 0).mean() * 100:.1f}%, ghost at termination {(c_end > 0).mean() * 100:.1f}%")
     print(f"   visited set: overflow list used by {(ovf > 0).mean() * 100:.1f}% (max {ovf.max()}), tier 2 by {t2.sum()} queries (max ids {n2.max()})")
+    t0 = dg[:, 4].astype(np.int64)
+    t0 = (t0 - t0.min()) & 0xFFFFFFFF
+    end = t0 / 100.0 + wall
+    sync_us = dg[:, 5] / 100.0
+    print(f"   replay: {sync_us[syncs > 0].mean() if (syncs > 0).any() else 0:.0f} us per synced query = {sync_us.sum() / max(rep.sum(), 1):.2f} us per replayed hop; kernel span {end.max():.0f} us, "
+          f"last starts at {t0.max() / 100.0:.0f} us; the 5 last to finish: " + "; ".join(f"start {t0[i] / 100.0:.0f} wall {wall[i]:.0f} (replay {sync_us[i]:.0f}) hops {hops[i]}" for i in np.argsort(-end)[:5]))
     top = np.argsort(-wall)[:8]
     print("   slowest: " + "; ".join(f"{wall[i]:.0f}us hops={hops[i]} syncs={syncs[i]} rep={rep[i]} ovf={ovf[i]} t2={n2[i]}" for i in top), flush=True)
