@@ -5,17 +5,21 @@ Metric: queries / wall second of the batched search call INCLUDIN
 copy of the labels, index upload excluded -- the clock runs around the whole query loop as in the reference's
 HnswSlimStrategy::solve (include/strategy/hnsw_slim_strategy.h:107-118).
 
-One "step" = a block of `--batches-per-step` (10) batches of 10 000 queries.  Every batch is a DISTINCT pre-generated
+One "step" = a block of `--batches-per-step` (100) batches of 10 000 queries.  Every batch is a DISTINCT pre-generated
 query set in page-locked host memory (8 sets, rotated); a batch is: H2D of its queries, the search
 (HierarchicalNSWSlim::searchKnn(q,k,tableint*) for every query), D2H of its labels.  Batches are issued round-robin on
 `--streams` HIP streams through the C ABI's asynchronous host-pointer entry (hs_search_batch_async), so copies and
-kernels of consecutive batches overlap as in a serving loop; 20 steps = 200 batches inside the timed region.
+kernels of consecutive batches overlap as in a serving loop; 20 steps = 2000 batches (about 2 s) inside the timed region.
+Every batch's labels are CONSUMED before its output buffer is reused: the host waits on the batch's event and compares a
+checksum of the labels that came back with the reference answers of that query set (the last batch of every stream is
+compared label by label), and hs_search_check's counters are sticky, so a capacity failure in any batch is reported.
 Workload: SIFT-1M-like d=128 L2, M=16 efC=200, Slim defaults, k=10; ef_search = the smallest value of the sweep whose
 recall@10 >= 0.95 on this data (all sweep points are reported in `config`).
 
-Multi-GPU (torchrun, one rank per GPU): the index is replicated; `--scaling weak` (default): every rank searches its own
-batches and the per-rank top-k labels are joined by one RCCL all-gather per batch; `--scaling strong`: ONE 10k batch is
-split into contiguous shards over the ranks (BASELINE.json configs[3]) and all-gathered.
+Multi-GPU (torchrun, one rank per GPU): the index is replicated; `--scaling strong` (the default for N > 1): ONE 10k batch is
+split into contiguous shards over the ranks (BASELINE.json configs[3]) and the per-rank top-k labels are joined by one RCCL
+all-gather per batch -- this is `value`; the weak figure (every rank searches its own 10k batches) is measured right after on a
+shorter region and reported as a side field.  Only rank 0 sweeps ef and computes ground truth; the ranks share its choice.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline accounting.
 """
@@ -57,6 +61,12 @@ def recall_at_k(labels, gt):
     return hits / gt.size
 
 
+def checksum(labels):
+    """Order-independent fingerprint of a [nq, k] label block: (sum, xor) -- two batches with the same per-query label SETS agree."""
+    v = np.ascontiguousarray(labels).ravel().astype(np.uint64)
+    return int(v.sum()), int(np.bitwise_xor.reduce(v))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,9 +83,9 @@ def main():
     ap.add_argument("--cand-cap", type=int, default=0)
     ap.add_argument("--hash-slots", type=int, default=0)
     ap.add_argument("--streams", type=int, default=16, help="HIP streams the batches are issued on round-robin (batches in flight); 1 = strictly serial")
-    ap.add_argument("--batches-per-step", type=int, default=10)
+    ap.add_argument("--batches-per-step", type=int, default=100)
     ap.add_argument("--query-sets", type=int, default=8, help="distinct pre-generated query batches rotated through")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto", help="auto: strong (one batch split over the ranks) when --gpus > 1")
     args = ap.parse_args()
 
     import torch
@@ -106,7 +116,7 @@ def main():
     threads = args.build_threads or min(len(os.sched_getaffinity(0)) or 8, 64)
     N, D, NQ, K = args.n, args.dim, args.nq, args.k
     BPS, NB, S = max(1, args.batches_per_step), max(1, args.query_sets), max(1, args.streams)
-    strong = args.scaling == "strong" and world > 1
+    strong = world > 1 and args.scaling in ("auto", "strong")
 
     # ---- data + index: rank 0 builds once and publishes a marker file; the other ranks generate their query sets
     #      meanwhile and wait on the file system, not inside a collective --------------------------------------------
@@ -135,9 +145,8 @@ def main():
         np.save(bpath, base)
         open(ready, "w").write("ok")
         log(f"build {t_build:.1f}s, convertFromHNSW {t_conv:.1f}s")
-    # query sets: weak -> this rank's own batches; strong -> the same global batches on every rank
-    qseed = (lambda b: 456 + b) if strong or world == 1 else (lambda b: 456 + 100 * rank + b)
-    query_sets = [headline_data(NQ, D, qseed(b)) for b in range(NB)]
+    # query sets: the same global batches on every rank (strong: each rank takes its shard of a batch; weak: each rank searches them whole)
+    query_sets = [headline_data(NQ, D, 456 + b) for b in range(NB)]
     while not os.path.exists(ready):
         time.sleep(0.5)
     base = np.load(bpath, mmap_mode="r")
@@ -146,13 +155,8 @@ def main():
     info = ix.info()
     if args.cand_cap or args.hash_slots:
         ix.set_capacity(args.cand_cap, args.hash_slots)
-    base_t = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
     q_sets_t = [torch.from_numpy(q).to(dev) for q in query_sets]
-    gts = [ground_truth(torch, base_t, q, K, hs) for q in q_sets_t]
-    del base_t
-    torch.cuda.empty_cache()
-    q_t, gt = q_sets_t[0], gts[0]
-
+    q_t = q_sets_t[0]
     d_labels = torch.empty((NQ, K), dtype=torch.int32, device=dev)
     d_counts = torch.empty((NQ,), dtype=torch.int32, device=dev)
     d_stats = torch.empty((NQ, 4), dtype=torch.int32, device=dev)
@@ -163,143 +167,173 @@ def main():
         ix.search_ids_dev(q_t if q is None else q, K, d_labels, None, d_counts, d_stats if stats else None, stream)
         ix.check(stream)
 
-    # ---- ef sweep on query set 0 (device-resident, one launch at a time): recall + counters; pick the operating point ----
-    sweep = {}
+    # ---- rank 0 only: ground truth, the ef sweep on query set 0 (device-resident, one launch at a time), the operating point:
+    #      the smallest sweep ef whose recall@10 >= 0.95 over ALL the query sets of the timed region --------------------------
+    sweep, chosen, recall, recalls = {}, 0, 0.0, []
     efs = [args.ef] if args.ef else [32, 48, 64, 68, 70, 72, 80, 96, 128, 192, 256]
-    chosen = None
-    for ef in efs:
-        run(ef, stats=True)
-        torch.cuda.synchronize()
-        lab = d_labels.cpu().numpy().astype(np.uint32)
-        st = d_stats.cpu().numpy().astype(np.int64)
-        rec = recall_at_k(lab, gt)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        run(ef)
-        e0.record()
-        for _ in range(3):
-            run(ef)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 3
-        bytes_q = st[:, 0] * 4 * D + st[:, 2] * 4 + st[:, 1] * 8
-        sweep[ef] = dict(recall=round(rec, 4), single_launch_qps=round(NQ / ms * 1e3), n_dist=round(float(st[:, 0].mean()), 1),
-                         n_hops=round(float(st[:, 1].mean()), 1), bytes_per_query=round(float(bytes_q.mean())),
-                         fallback=int((st[:, 3] != 0).sum()), alg_GBs=round(float(bytes_q.sum()) / ms / 1e6, 1))
-        if rank == 0:
-            log(f"ef={ef}: {sweep[ef]}")
-        if chosen is None and rec >= 0.95:
-            chosen = ef
-            if not args.ef and os.environ.get("HS_BENCH_FULL_SWEEP", "1") == "0":
-                break
-    if chosen is None:
-        chosen = efs[-1]
-    if world > 1:  # all ranks must time the same ef
-        c = torch.tensor([chosen], device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.MAX)
-        chosen = int(c.item())
-    # reference answers + algorithmic bytes of every query set at the operating point; the operating point must hold
-    # recall@10 >= 0.95 over ALL the query sets of the timed region, not only on the set the sweep ran on
-    while True:
-        ix.set_ef(chosen)
-        ref_labels, alg_bytes, recalls = [], [], []
-        for b in range(NB):
-            run(chosen, q_sets_t[b], stats=True)
+    if rank == 0:
+        base_t = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
+        gts = [ground_truth(torch, base_t, q, K, hs) for q in q_sets_t]
+        del base_t
+        torch.cuda.empty_cache()
+        for ef in efs:
+            run(ef, stats=True)
             torch.cuda.synchronize()
-            st = d_stats.cpu().numpy().astype(np.int64)
-            alg_bytes.append(float((st[:, 0] * 4 * D + st[:, 2] * 4 + st[:, 1] * 8).sum()))
             lab = d_labels.cpu().numpy().astype(np.uint32)
-            ref_labels.append(np.sort(lab, axis=1))
-            recalls.append(recall_at_k(lab, gts[b]))
-        recall = float(np.mean(recalls))
-        ok = torch.tensor([1 if recall >= 0.95 else 0], device=dev)
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        later = [e for e in efs if e > chosen]
-        if int(ok.item()) or args.ef or not later:
-            break
-        if rank == 0:
+            st = d_stats.cpu().numpy().astype(np.int64)
+            rec = recall_at_k(lab, gts[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run(ef)
+            e0.record()
+            for _ in range(3):
+                run(ef)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            bytes_q = st[:, 0] * 4 * D + st[:, 2] * 4 + st[:, 1] * 8
+            sweep[ef] = dict(recall=round(rec, 4), single_launch_qps=round(NQ / ms * 1e3), n_dist=round(float(st[:, 0].mean()), 1),
+                             n_hops=round(float(st[:, 1].mean()), 1), bytes_per_query=round(float(bytes_q.mean())),
+                             fallback=int((st[:, 3] != 0).sum()), alg_GBs=round(float(bytes_q.sum()) / ms / 1e6, 1), kernel=ix.last_kernel())
+            log(f"ef={ef}: {sweep[ef]}")
+            if not chosen and rec >= 0.95:
+                chosen = ef
+                if not args.ef and os.environ.get("HS_BENCH_FULL_SWEEP", "1") == "0":
+                    break
+        chosen = chosen or efs[-1]
+        while True:
+            recalls = []
+            for b in range(NB):
+                run(chosen, q_sets_t[b])
+                torch.cuda.synchronize()
+                recalls.append(recall_at_k(d_labels.cpu().numpy().astype(np.uint32), gts[b]))
+            recall = float(np.mean(recalls))
+            later = [e for e in efs if e > chosen]
+            if recall >= 0.95 or args.ef or not later:
+                break
             log(f"ef={chosen}: recall@10 {recall:.4f} over the {NB} query sets < 0.95 -> next sweep point")
-        chosen = later[0]
+            chosen = later[0]
+    if world > 1:  # every rank times rank 0's operating point
+        c = torch.tensor([chosen], device=dev)
+        dist.broadcast(c, src=0)
+        chosen = int(c.item())
+    # reference answers (this rank's own device) + algorithmic bytes of every query set at the operating point
+    ix.set_ef(chosen)
+    ref_labels, ref_sums, alg_bytes = [], [], []
+    for b in range(NB):
+        run(chosen, q_sets_t[b], stats=True)
+        torch.cuda.synchronize()
+        st = d_stats.cpu().numpy().astype(np.int64)
+        alg_bytes.append(float((st[:, 0] * 4 * D + st[:, 2] * 4 + st[:, 1] * 8).sum()))
+        lab = d_labels.cpu().numpy().astype(np.uint32)
+        ref_labels.append(np.sort(lab, axis=1))
+        ref_sums.append(checksum(lab))
+    kernel_name = ix.last_kernel()
     alg_bytes_launch = float(np.mean(alg_bytes))
 
-    # ---- the timed region ------------------------------------------------------------------------------------------
+    # ---- the timed region(s) ------------------------------------------------------------------------------------------
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    lo, hi = sharded.shard_range(NQ, rank, world) if strong else (0, NQ)
-    rows = hi - lo
-    if world == 1:
-        # product path: page-locked host buffers in, page-locked host buffers out, hs_search_batch_async on the stream
-        q_pin = [hs.PinnedArray((NQ, D), np.float32) for _ in range(NB)]
-        for b in range(NB):
-            q_pin[b].a[:] = query_sets[b]
-        out_pin = [hs.PinnedArray((NQ, K), np.uint32) for _ in range(S)]
+    events = [torch.cuda.Event() for _ in range(S)]
+
+    def timed(strong_mode, steps, warmup):
+        """One timed region; returns (elapsed seconds, batches).  Every batch is consumed: before a stream's output buffer is
+        reused the host waits for that stream's previous batch and checks the checksum of its labels."""
+        lo, hi = sharded.shard_range(NQ, rank, world) if strong_mode else (0, NQ)
+        rows = hi - lo
         last_on = [-1] * S
-
-        def batch(j):
-            s = j % S
-            last_on[s] = j % NB
-            ix.search_ids_async(q_pin[j % NB].a, K, out_pin[s].a, streams[s].cuda_stream)
-    else:
-        # one rank per GPU: H2D, hs_search_batch_dev, RCCL all-gather of the labels, D2H of the gathered [world*rows x K]
-        q_pin = [torch.from_numpy(query_sets[b][lo:hi].copy()).pin_memory() for b in range(NB)]
-        q_dev = [torch.empty((rows, D), dtype=torch.float32, device=dev) for _ in range(S)]
-        lab_dev = [torch.empty((rows, K), dtype=torch.int32, device=dev) for _ in range(S)]
-        cnt_dev = [torch.empty((max(rows, 1),), dtype=torch.int32, device=dev) for _ in range(S)]
-        tot = NQ if strong else world * NQ
-        out_pin = [torch.empty((tot, K), dtype=torch.int32).pin_memory() for _ in range(S)]
-        last_on = [-1] * S
-
-        def batch(j):
-            s = j % S
-            last_on[s] = j % NB
-            with torch.cuda.stream(streams[s]):
-                q_dev[s].copy_(q_pin[j % NB], non_blocking=True)
-                if rows:
-                    ix.search_ids_dev(q_dev[s], K, lab_dev[s], None, cnt_dev[s], None, streams[s].cuda_stream)
-                full = sharded.all_gather_rows(lab_dev[s], tot, world, rank)  # RCCL over xGMI: every rank holds all top-k
-                out_pin[s].copy_(full, non_blocking=True)
-
-    def finish():
-        for st_ in streams:
-            ix.check(st_.cuda_stream)  # synchronises the stream and reports capacity errors
-
-    torch.cuda.synchronize()
-    for j in range(args.warmup * BPS):
-        batch(j)
-    finish()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for j in range(args.steps * BPS):
-        batch(j)
-    finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # what came back through the timed path == the reference answers of that query set
-    for s in range(S):
-        if last_on[s] < 0:
-            continue
-        got = out_pin[s].a if world == 1 else out_pin[s].numpy().astype(np.uint32)
         if world == 1:
-            assert np.array_equal(np.sort(got, axis=1), ref_labels[last_on[s]]), "timed path returned different labels"
-        elif strong:
-            assert np.array_equal(np.sort(got[lo:hi], axis=1), ref_labels[last_on[s]][lo:hi]), "timed path returned different labels"
+            # product path: page-locked host buffers in, page-locked host buffers out, hs_search_batch_async on the stream
+            q_pin = [hs.PinnedArray((NQ, D), np.float32) for _ in range(NB)]
+            for b in range(NB):
+                q_pin[b].a[:] = query_sets[b]
+            out_pin = [hs.PinnedArray((NQ, K), np.uint32) for _ in range(S)]
+            out_np = [o.a for o in out_pin]
+
+            def issue(j, s):
+                ix.search_ids_async(q_pin[j % NB].a, K, out_np[s], streams[s].cuda_stream)
+
+            def mine(s):
+                return out_np[s], last_on[s], slice(0, NQ)
         else:
-            assert np.array_equal(np.sort(got[rank * NQ:(rank + 1) * NQ], axis=1), ref_labels[last_on[s]]), "timed path returned different labels"
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    n_batches = args.steps * BPS
+            # one rank per GPU: H2D, hs_search_batch_dev, RCCL all-gather of the labels, D2H of the gathered [tot x K]
+            q_pin = [torch.from_numpy(query_sets[b][lo:hi].copy()).pin_memory() for b in range(NB)]
+            q_dev = [torch.empty((rows, D), dtype=torch.float32, device=dev) for _ in range(S)]
+            lab_dev = [torch.empty((rows, K), dtype=torch.int32, device=dev) for _ in range(S)]
+            cnt_dev = [torch.empty((max(rows, 1),), dtype=torch.int32, device=dev) for _ in range(S)]
+            tot = NQ if strong_mode else world * NQ
+            out_pin = [torch.empty((tot, K), dtype=torch.int32).pin_memory() for _ in range(S)]
+            out_np = [o.numpy().view(np.uint32) for o in out_pin]
+
+            def issue(j, s):
+                with torch.cuda.stream(streams[s]):
+                    q_dev[s].copy_(q_pin[j % NB], non_blocking=True)
+                    if rows:
+                        ix.search_ids_dev(q_dev[s], K, lab_dev[s], None, cnt_dev[s], None, streams[s].cuda_stream)
+                    full = sharded.all_gather_rows(lab_dev[s], tot, world, rank)  # RCCL over xGMI: every rank holds all top-k
+                    out_pin[s].copy_(full, non_blocking=True)
+
+            def mine(s):   # strong: the whole gathered batch; weak: this rank's block of the gathered [world x NQ] rows
+                return out_np[s], last_on[s], (slice(0, NQ) if strong_mode else slice(rank * NQ, (rank + 1) * NQ))
+
+        def consume(s, full=False):
+            if last_on[s] < 0:
+                return
+            events[s].synchronize()
+            got, b, sl = mine(s)
+            if full:
+                assert np.array_equal(np.sort(got[sl], axis=1), ref_labels[b]), "timed path returned different labels"
+            else:
+                assert checksum(got[sl]) == ref_sums[b], "timed path returned different labels"
+
+        def batch(j):
+            s = j % S
+            consume(s)
+            issue(j, s)
+            events[s].record(streams[s])
+            last_on[s] = j % NB
+
+        def finish():
+            for s_, st_ in enumerate(streams):
+                consume(s_, full=True)
+                last_on[s_] = -1
+                ix.check(st_.cuda_stream)  # synchronises the stream; the counters are sticky: any batch's capacity failure shows here
+
+        torch.cuda.synchronize()
+        for j in range(warmup * BPS):
+            batch(j)
+        finish()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(steps * BPS):
+            batch(j)
+        finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, steps * BPS, rows
+
+    elapsed, n_batches, rows = timed(strong, args.steps, args.warmup)
     total_queries = (NQ if strong else world * NQ) * n_batches
     qps = total_queries / elapsed
+    weak_side = None
+    if strong:   # the weak figure beside it: every rank searches whole 10k batches (a quarter of the steps)
+        w_el, w_nb, _ = timed(False, max(args.steps // 4, 1), max(args.warmup // 4, 1))
+        weak_side = round(world * NQ * w_nb / w_el, 1)
 
     # ---- side figures (never `value`): one launch alone on the GPU, device-resident pipelined rate -------------------
+    def finish_all():
+        for st_ in streams:
+            ix.check(st_.cuda_stream)
+
     ke0, ke1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kern_ms = []
-    for i in range(max(args.steps, 10)):
+    for i in range(max(min(args.steps, 40), 10)):
         qq = q_sets_t[i % NB]
         ke0.record()
         ix.search_ids_dev(qq, K, d_labels, None, d_counts, None, stream)
@@ -311,10 +345,10 @@ def main():
     outs = [(torch.empty((NQ, K), dtype=torch.int32, device=dev), torch.empty((NQ,), dtype=torch.int32, device=dev)) for _ in range(S)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for j in range(4 * S):
+    for j in range(16 * S):
         ix.search_ids_dev(q_sets_t[j % NB], K, outs[j % S][0], None, outs[j % S][1], None, streams[j % S].cuda_stream)
-    finish()
-    dev_resident_qps = 4 * S * NQ / (time.perf_counter() - t0)
+    finish_all()
+    dev_resident_qps = 16 * S * NQ / (time.perf_counter() - t0)
     sync_host_qps = None
     if rank == 0 and world == 1:   # the synchronous host-pointer entry on pageable memory
         ix.search_ids(query_sets[0], K)
@@ -327,35 +361,62 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from hsutil import Oracle
-        ox = Oracle().load(spath, "slim", 0, D)
-        ox.set_ef(chosen)
-        cores = min(len(os.sched_getaffinity(0)) or 1, 64)
-        ns = min(NQ, 2000)
-        t0 = time.perf_counter()
-        ox.search_ids(query_sets[0][:ns], K, threads=1, raw=False)
-        t1 = time.perf_counter() - t0
-        reps, tN, same = 0, 0.0, True
-        while tN < 10.0 and reps < 4 * NB:   # about 10 s of CPU work
+        threads_all = min(len(os.sched_getaffinity(0)) or 1, 64)
+        model, phys = "unknown", set()
+        try:
+            core = pkg = None
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    pkg = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        phys.add((pkg, core))
+                    core = pkg = None
+        except OSError:
+            pass
+
+        def cpu_run(variant, budget_s):
+            ox = Oracle(variant).load(spath, "slim", 0, D)
+            ox.set_ef(chosen)
+            ns = min(NQ, 2000)
             t0 = time.perf_counter()
-            rN = ox.search_ids(query_sets[reps % NB], K, threads=cores, raw=False)
-            tN += time.perf_counter() - t0
-            same = same and bool(np.array_equal(np.sort(rN["labels"], axis=1), ref_labels[reps % NB]))
-            reps += 1
-        cpu = dict(value=round(reps * NQ / tN, 1), unit="queries/s", cores=cores, kind="port",
-                   sample=f"{reps} batches of {NQ} queries (the bench's query sets), OpenMP dynamic over {cores} threads, ef={chosen}; "
-                          f"serial (as shipped, 1 core) on the first {ns} queries: {ns / t1:.0f} queries/s",
-                   serial_qps=round(ns / t1, 1), gpu_label_sets_identical=same)
+            ox.search_ids(query_sets[0][:ns], K, threads=1, raw=False)
+            t1 = time.perf_counter() - t0
+            reps, tN, same = 0, 0.0, True
+            while tN < budget_s and reps < 4 * NB:
+                t0 = time.perf_counter()
+                rN = ox.search_ids(query_sets[reps % NB], K, threads=threads_all, raw=False)
+                tN += time.perf_counter() - t0
+                same = same and bool(np.array_equal(np.sort(rN["labels"], axis=1), ref_labels[reps % NB]))
+                reps += 1
+            return reps * NQ / tN, ns / t1, reps, same
+
+        q_par, q_ser, reps, same = cpu_run("", 10.0)
+        of_par, of_ser, of_reps, of_same = cpu_run("_ofast", 6.0)
+        cpu = dict(value=round(q_par, 1), unit="queries/s", cores=threads_all, kind="port",
+                   sample=f"{reps} batches of {NQ} queries (the bench's query sets), OpenMP dynamic over {threads_all} threads, ef={chosen}; "
+                          f"serial (as shipped, 1 core) on the first 2000 queries: {q_ser:.0f} queries/s",
+                   serial_qps=round(q_ser, 1), gpu_label_sets_identical=same,
+                   cpu_model=model, physical_cores_visible=len(phys) or None, hardware_threads_used=threads_all,
+                   compiler="g++ (oracle/Makefile, built in the build container)", flags="-O3 -march=native -ffp-contract=off -fno-fast-math -fopenmp (the pinned parity flags)",
+                   ofast={"flags": "-Ofast -flto -march=native -fopenmp (/root/reference/CMakeLists.txt:14)", "value": round(of_par, 1), "serial_qps": round(of_ser, 1),
+                          "batches": of_reps, "label_sets_identical_to_gpu": of_same})
 
     if rank == 0:
         # HBM traffic (PMC) cannot be collected from inside this process; the committed profile of this same workload is quoted
         traffic, tsrc = None, None
-        for name in ("r02_traffic.json", "r02_traffic_ef70.json", "r01_traffic.json"):   # (the operating point is 68 or 70 depending on the graph the box built)
+        for name in ("r03_traffic.json", "r02_traffic.json", "r02_traffic_ef70.json"):   # (the operating point is 68 or 70 depending on the graph the box built)
             tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tpath) and N == 1_000_000 and NQ == 10_000 and D == 128 and chosen == json.load(open(tpath)).get("ef"):
-                traffic, tsrc = json.load(open(tpath))["hbm_bytes_per_launch"], "profiles/" + name
-                break
-        # which search kernel serves this shape (csrc/capi.cpp: the lean kernel from ef = 64 on L2 d = 96 / 128, else the fast kernel)
-        kname = "hs::lean_kernel" if (chosen >= 64 and D in (96, 128)) else "hs::fast_kernel"
+            if os.path.exists(tpath) and N == 1_000_000 and NQ == 10_000 and D == 128:
+                tj = json.load(open(tpath))
+                if chosen == tj.get("ef") and tj.get("kernel", "hs::lean_kernel") == kernel_name:
+                    traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + name
+                    break
+        kname = kernel_name   # the kernel the library chose for this shape (hs_last_kernel)
         step_ms = elapsed / args.steps * 1e3
         batch_ms = elapsed / n_batches * 1e3
         achieved_single = alg_bytes_launch / (kern_ms * 1e-3) / 1e9   # one launch alone on the GPU
@@ -367,23 +428,24 @@ def main():
             "config": {"workload": f"SIFT-1M-like d={D} L2, N={N}, batch={NQ} queries" + ("" if strong else "/GPU") +
                                    f", HNSW-Slim M=16 efC=200 (Slim defaults), k={K}, ef_search={chosen}",
                        "step": f"1 step = {BPS} batches; each batch = H2D of {rows if strong else NQ} queries (one of {NB} distinct page-locked sets, rotated) + search + "
-                               + ("RCCL all-gather of the labels + " if world > 1 else "") + "D2H of the labels",
-                       "batches_timed": n_batches, "ms_per_batch": round(batch_ms, 4),
+                               + ("RCCL all-gather of the labels + " if world > 1 else "") + "D2H of the labels; every batch's labels are checked (checksum) before its buffer is reused",
+                       "batches_timed": n_batches, "ms_per_batch": round(batch_ms, 4), "timed_seconds": round(elapsed, 3),
                        "pipelining": f"batches issued round-robin on {S} HIP streams (up to {S} in flight)",
                        "entry": "hs_search_batch_async (host pointers)" if world == 1 else "hs_search_batch_dev + torch.distributed all_gather_into_tensor",
                        "ef_search": chosen, "recall_at_10": round(recall, 4), "recall_per_query_set": [round(r, 4) for r in recalls],
                        "sweep": sweep, "index": info, "build_s": round(t_build, 1), "convert_s": round(t_conv, 1), "build_threads": threads,
                        "device_resident_pipelined_qps": round(dev_resident_qps, 1), "single_launch_qps": round(NQ / kern_ms * 1e3, 1),
-                       "sync_host_pointer_api_qps_pageable": sync_host_qps},
+                       "sync_host_pointer_api_qps_pageable": sync_host_qps,
+                       "weak_scaling_qps_side_figure": weak_side},
             # achieved/frac: algorithmic bytes of one 10k-query launch / the HIP-event duration of that launch alone on the GPU
-            # (what a rocprofv3 kernel-trace average of the search kernel measures, profiles/r02_kernel_stats_1stream.csv);
+            # (what a rocprofv3 kernel-trace of the search kernel's dispatches adds up to, profiles/r03_kernel_stats_1stream.csv);
             # timed_region_*: the same bytes / the effective per-batch time of the timed region (S batches in flight, PCIe included).
             "roofline": {"bound": "hbm", "achieved": round(achieved_single, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_single / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "kernel": kname, "launch_ms": round(kern_ms, 4),
                          "launch": f"one 10k-query pass = {kname[4:]} (upper-level descent) + order_kernel (start order) + {kname[4:]} "
-                                   f"(level-0 search); launch_ms spans the three, a rocprofv3 kernel trace shows two {kname[4:]} "
-                                   "dispatches per pass whose durations add up to it (profiles/r02_kernel_stats_1stream.csv)",
+                                   f"(level-0 search) + the (normally empty) re-run scan; launch_ms spans them, a rocprofv3 kernel trace shows two "
+                                   f"{kname[4:]} dispatches per pass whose durations add up to it",
                          "timed_region_achieved": round(eff, 1), "timed_region_frac": round(eff / HBM_PEAK_GBS, 4),
                          "launches_in_flight": S, "algorithmic_bytes_per_launch": alg_bytes_launch},
             "cpu_baseline": cpu,

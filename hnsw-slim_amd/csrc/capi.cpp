@@ -139,7 +139,6 @@ static uint32_t next_pow2(uint32_t v) {
 struct Shape {
   uint32_t ef, cand_cap, cand_cap_fast, hash_slots;
   uint32_t q_hash_slots, q_bits;        // fast kernel: visited-set tier 1 in 16-bit slots (LDS words, id-space width; 0 = not applicable)
-  uint32_t g_cand_cap, g_hash_slots;    // group kernel (four queries per wavefront): per-query LDS shares
   uint32_t l_cand_cap, l_hash_slots;    // lean kernel
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
@@ -187,34 +186,6 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
     s.q_bits = (!off && B - bbits <= 16 && B < 32) ? B : 0;
   }
   const uint32_t dim = (uint32_t)ix->info.dim;
-  // Group kernel: LDS is what bounds the queries resident per CU, so the shares cover most queries (candidate heap: ~p99 of
-  // the peak size, visited set: ~p90 of the distance evaluations, measured on the 1M SIFT-like bench index for ef 32..256)
-  // and the rest continue in their tier-2 regions; then both are trimmed by up to 12 % if that admits one more wavefront per CU.
-  {
-    uint32_t gc = ix->user_cand_cap ? ix->user_cand_cap : (uint32_t)((2.5 * ef + 130) * (1u << ix->grow_cand));
-    uint32_t gh = ix->user_hash_slots ? ix->user_hash_slots : (uint32_t)((520 + 5 * ef) * (1.0 + 0.25 * ix->grow_hash) / 0.875);
-    gc = std::max<uint32_t>((gc + 1) & ~1u, 16);
-    gh = std::max<uint32_t>((gh + 3) & ~3u, std::max<uint32_t>(64, (uint32_t)(2 * (ef + 1) + 3) & ~3u));   // replay heap lives there
-    const bool qr = group_q_in_regs(ix->info.metric, dim);
-    if (!ix->user_cand_cap && !ix->user_hash_slots) {
-      const size_t per_wave = group_lds_bytes(dim, gc, gh, qr);
-      const size_t waves = per_wave ? kLdsPerCU / per_wave : 0;
-      if (waves >= 1 && waves < 8) {
-        const uint32_t gc2 = std::max<uint32_t>(((uint32_t)(gc * 0.88) + 1) & ~1u, 16), gh2 = std::max<uint32_t>(((uint32_t)(gh * 0.88) + 3) & ~3u, (uint32_t)(2 * (ef + 1) + 3) & ~3u);
-        if (group_lds_bytes(dim, gc2, gh2, qr) * (waves + 1) <= kLdsPerCU) {
-          // largest shares that still fit waves + 1 wavefronts
-          uint32_t c = gc, h = gh;
-          while (group_lds_bytes(dim, c, h, qr) * (waves + 1) > kLdsPerCU) {
-            if (h > gh2) h -= 4;
-            if (c > gc2) c -= 2;
-          }
-          gc = c; gh = h;
-        }
-      }
-    }
-    s.g_cand_cap = gc;
-    s.g_hash_slots = gh;
-  }
   // Lean kernel (large ef): candidate heap ~p99 of its peak size, visited set ~p90 of the distance evaluations at an 87.5 % fill
   // limit (measured on the 1M SIFT-like bench index, ef 32..256); the rest continue in their tier-2 regions.
   {
@@ -781,28 +752,23 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     a.hash_slots = on ? fast_hash : sh.hash_slots;
     a.vis_bits = on ? sh.q_bits : 0;
   };
-  // The four-queries-per-wavefront kernel (group_search.hip) is parity-green but measured slower than the one-query-per-wave
-  // fast kernel on MI355X: HS_GROUP=1 selects it for A/B runs and for its parity tests.
-  static const bool use_group = getenv("HS_GROUP") != nullptr;
-  const bool group = use_group && !ix->exact_order && !raw && group_supported(ix->dev, sh.ef, (uint32_t)k) &&
-                     group_lds_bytes((uint32_t)ix->info.dim, sh.g_cand_cap, sh.g_hash_slots, group_q_in_regs(ix->info.metric, (uint32_t)ix->info.dim)) <= kLdsPerCU;
   // The lean kernel answers from HS_LEAN_MIN_EF upwards (diagnostic knob; default: see kLeanMinEf)
   static const uint32_t lean_min_ef = getenv("HS_LEAN_MIN_EF") ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
   static const bool lean_forced = getenv("HS_LEAN_MIN_EF") != nullptr;   // the parity tests force it on every shape it supports
   const uint32_t lean_from = lean_forced ? lean_min_ef : (ix->integer_data ? kLeanMinEf : kLeanMinEfContinuous);
-  const bool lean = !group && fast && sh.ef >= lean_from && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
+  const bool lean = fast && sh.ef >= lean_from && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
                     lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots) <= kLdsPerCU;
   // The flat kernel (lazy candidate heap, flat_search.hip) answers every bare index it supports; HS_KERNEL=lean|fast selects the
   // older kernels for A/B runs and for their parity tests, HS_KERNEL=flat forces it.
   static const char *kernel_env = getenv("HS_KERNEL");
   static const bool flatk_off = kernel_env && (!strcmp(kernel_env, "lean") || !strcmp(kernel_env, "fast"));
   const FlatPlan fp = plan_flat(ix, sh.ef, nq);
-  const bool flatk = !flatk_off && !group && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);
-  ix->last_kernel = flatk ? "hs::flat_kernel" : lean ? "hs::lean_kernel" : group ? "hs::group_kernel" : fast ? "hs::fast_kernel" : "hs::strict_kernel";
+  const bool flatk = !flatk_off && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);
+  ix->last_kernel = flatk ? "hs::flat_kernel" : lean ? "hs::lean_kernel" : fast ? "hs::fast_kernel" : "hs::strict_kernel";
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;
   static const int order_env = getenv("HS_ORDER") ? atoi(getenv("HS_ORDER")) : -1;   // diagnostic: 0 = never, 1 = always
-  const bool ordered = fast && !group && (order_env < 0 ? nq >= kOrderMinQueries : order_env != 0);
+  const bool ordered = fast && (order_env < 0 ? nq >= kOrderMinQueries : order_env != 0);
   if (flatk) {
     // pass 0: the flat kernel; a query that exhausts its scratch is left ST_OVERFLOW, one whose logs did not fit ST_HAZARD
     a.hash_slots = fp.nb * 4; a.vis_bits = fp.vis_bits; a.fl_nb = fp.nb; a.fl_mul = fp.mul; a.fl_sh = fp.sh;
@@ -839,19 +805,6 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
       HIP_TRY(launch_lean(ix->dev, a, stream));
     }
     a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots; a.hash_fill_shift = 0; a.vis_bits = 0;
-  } else if (group) {
-    // pass 0: the group kernel (four queries per wavefront, persistent grid) answers every query; one whose scratch runs
-    // out even in its tier-2 regions is left ST_OVERFLOW for the one-query-per-wave kernels below
-    a.cand_cap = sh.g_cand_cap; a.hash_slots = sh.g_hash_slots;
-    a.select_mask = 1u << ST_TODO; a.grid = (uint32_t)nq;
-    HIP_TRY(launch_group(ix->dev, a, stream));
-    a.cand_cap = sh.cand_cap; a.hash_slots = sh.hash_slots;
-    if (fast) {
-      fast_scratch(true);
-      a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.pass_id = 3;
-      HIP_TRY(launch_fast(ix->dev, a, stream));
-      fast_scratch(false);
-    }
   } else {
     if (fast) fast_scratch(true);
     // pass 0: every query, one wavefront each
@@ -880,7 +833,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   // the whole-CU pass exists: a batch is then two kernel launches, not three.
   const bool big_pass = sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots;
   // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
-  if ((fast || group || lean || flatk) && !big_pass) {
+  if ((fast || lean || flatk) && !big_pass) {
     a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
     a.counters = w->counters.p + 4; a.pass_id = 1;
     HIP_TRY(launch_strict(ix->dev, a, stream));
@@ -889,7 +842,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   if (big_pass) {
     // few workgroups: each needs a whole CU's LDS, i.e. a CU drained of every other wave before it can start -- with
     // several batches in flight a wide grid of them stalls the stream even when (as usual) no query is flagged
-    a.select_mask = (1u << ST_OVERFLOW) | ((fast || group || lean || flatk) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, 16);
+    a.select_mask = (1u << ST_OVERFLOW) | ((fast || lean || flatk) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, 16);
     a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
     a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));
@@ -922,17 +875,6 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   HIP_TRY(hipMemcpyAsync(c, w->counters.p, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(c), (hipStream_t)stream));   // read and cleared: see search_dev_group
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  if (getenv("HS_GPROF") && w->counters.n >= 48) {   // diagnostic build (make gprof): per-phase shader clocks of the group kernel
-    unsigned long long g[16];
-    HIP_TRY(hipMemcpy(g, w->counters.p + 16, sizeof(g), hipMemcpyDeviceToHost));
-    static const char *nm[10] = {"refill", "push", "pop", "tile-wait", "ids+visited", "distances", "post", "accept", "next+request", "finish"};
-    unsigned long long tot = 0;
-    for (int i = 0; i < 10; i++) tot += g[i];
-    if (tot) {
-      fprintf(stderr, "[hs gprof] wave-rounds %llu  push-iters %llu  accept-iters %llu  dist-passes %llu  finish-events %llu  cycles/round %.0f\n", g[10], g[11], g[12], g[13], g[14], (double)tot / (double)std::max(1ull, g[10]));
-      for (int i = 0; i < 10; i++) fprintf(stderr, "[hs gprof]   %-14s %6.1f %%  %8.0f cycles/round\n", nm[i], 100.0 * g[i] / tot, (double)g[i] / (double)std::max(1ull, g[10]));
-    }
-  }
   // learn the scratch sizes from the data: if more than 1% of a batch overflowed in the first passes,
   // later batches start with twice the visited-set slots / candidate capacity.
   const size_t nq = std::max<size_t>(w->last_nq, 1);

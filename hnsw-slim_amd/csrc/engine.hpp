@@ -52,7 +52,7 @@ struct SearchArgs {
   uint32_t *status;      // nq
   uint32_t *counters;    // [0] visited-set overflows, [1] candidate-heap overflows, [2] tie hazards, [3] tier-2 spills (this pass)
   uint32_t pass_id;
-  uint32_t *queue;       // group kernel: device-wide query counter (zeroed per launch group)
+  uint32_t *queue;       // device-wide work counter (unused by the shipped kernels; zeroed per launch group)
   uint32_t hash_fill_shift;   // visited-set tier 1 is frozen at 1 - 2^-shift of its slots (0 = the default 2: 75 %)
   uint32_t flat;         // fast kernel: start the level-0 search without the candidate heap (beam_search.hip, FLAT)
   uint32_t hop_cap;      // bytes of the per-expansion accept counts behind the insertion log (one per expansion of the flat start)
@@ -87,17 +87,12 @@ bool lean_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 bool lean_preferred(const DevIndex &ix);   // shapes on which it beats the fast kernel at large ef (compile-time dims)
 size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
 hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
-// Group kernel (group_search.hip): four queries per wavefront, persistent grid; same contract as the fast kernel.
 // Flat kernel (flat_search.hip): lazy candidate heap -- replayed from the insertion log only when its layout decides a pop.
 bool flatk_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 size_t flatk_lds_bytes(uint32_t dim, uint32_t ef, uint32_t nb);
 hipError_t launch_flatk(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 hipError_t flat_heap_ops(const uint32_t *d_ops, uint32_t n_ops, uint2 *d_spill, uint2 *d_heap, uint2 *d_pops, uint32_t *d_n, int wave_pop,
                          uint32_t lds_slots, hipStream_t stream);
-bool group_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
-bool group_q_in_regs(int metric, uint32_t dim);
-size_t group_lds_bytes(uint32_t dim, uint32_t cand_cap, uint32_t hash_slots, bool q_in_regs);
-hipError_t launch_group(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 
 }  // namespace hs

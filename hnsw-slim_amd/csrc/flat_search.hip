@@ -423,7 +423,12 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
   uint32_t n_dist = 1, n_hops = 0, n_nbr = 0;
 #ifdef HS_FLAT_DIAG   // diagnostic build (make flatdiag): per-query wall clock and replay counts behind the stats block
   const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
-  uint32_t diag_syncs = 0, diag_replayed = 0, diag_sync_ticks = 0;
+  uint32_t diag_syncs = 0, diag_replayed = 0, diag_sync_ticks = 0, diag_pre = 0;
+  uint32_t diag_ph[6] = {0, 0, 0, 0, 0, 0};   // shader cycles: select | tile wait | visited + compaction | rows + distances | accept (+ pre-select) | hop end
+  unsigned long long diag_tp = __builtin_amdgcn_s_memtime();
+#define HS_DIAG_LAP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); diag_ph[i] += (uint32_t)(t_ - diag_tp); diag_tp = t_; }
+#else
+#define HS_DIAG_LAP(i)
 #endif
 
   // ---- stage the query, clear the visited set ---------------------------------------------------------------------------
@@ -574,6 +579,7 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
     inr[s] = hs_ballot((uint32_t)(lane * S + s) < ef);
   }
   const int laneS = lane * S;
+  const bool exact_fit = ef == 64u * S;   // no spare ranks behind ef - 1
   // visited_array[enterpoint] = tag of the (q,k) overloads (:1919; nothing reads the set before level 0) and
   // visited_array[currObj] = tag (:2100-2102): lane 0 marks the entry, lane 1 the enter point
   {
@@ -599,20 +605,23 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
   const uint32_t stride = ix.tile_stride;
   int rc = vfail ? 1 : 0;
 
-  while (rc == 0) {
-    // ---- the node to expand: minimum of candidate_set (:335-354) -------------------------------------------------------
+  // nearest unexpanded entry of the result set (ranks < ef): {found, its lane and slot, key, id, how many unexpanded entries share the key}
+  struct Near { bool any; int p, slot, key; uint32_t id, same; };
+  auto nearest = [&]() -> Near {
+    Near r;
     unsigned long long um[S], any = 0;
 #pragma unroll
     for (int s = 0; s < S; s++) {
       um[s] = hs_ballot((int)ti[s] >= 0) & inr[s];
       any |= um[s];
     }
-    uint32_t next_id = 0;
-    bool need_heap = ghost_key == lb;
+    r.any = any != 0;
+    r.p = 0; r.slot = 0; r.key = kFKeyInf; r.id = 0; r.same = 0;
     if (any) {
       const int p = __ffsll((long long)any) - 1;
       int u_key = __builtin_amdgcn_readlane(tk[S - 1], p);
       uint32_t u_id = __builtin_amdgcn_readlane(ti[S - 1], p);
+      int u_slot = S - 1;
 #pragma unroll
       for (int s = S - 2; s >= 0; s--) {
         const bool here = (um[s] >> p) & 1ull;
@@ -620,15 +629,42 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
         const uint32_t ii = __builtin_amdgcn_readlane(ti[s], p);
         u_key = here ? kk : u_key;
         u_id = here ? ii : u_id;
+        u_slot = here ? s : u_slot;
       }
       uint32_t same = 0;
 #pragma unroll
       for (int s = 0; s < S; s++) same += __popcll(hs_ballot(tk[s] == u_key) & um[s]);
-      need_heap = same > 1 || (need_heap && u_key == lb);
-      next_id = u_id;
-    } else if (!need_heap) {
-      break;   // nothing left that the reference could pop with dist <= lowerBound
+      r.p = p; r.slot = u_slot; r.key = u_key; r.id = u_id; r.same = same;
     }
+    return r;
+  };
+  // The node of the NEXT expansion is usually known before this expansion's accept pass has run (see the pass loop): its tile
+  // is then already on its way (pre_tile) while the accepted entries are inserted.
+  bool have_pre = false;
+  uint32_t pre_id = 0, pre_tile = kNone;
+  int pre_key = 0;
+
+  while (rc == 0) {
+    // ---- the node to expand: minimum of candidate_set (:335-354) -------------------------------------------------------
+    uint32_t next_id = 0, id = kNone;
+    bool need_heap = false;
+    if (have_pre && !(ghost_key == lb && pre_key == lb)) {   // (an entry evicted at the very key of the chosen node: the heap decides)
+      next_id = pre_id;
+      id = pre_tile;
+    } else {
+      if (have_pre) {   // take the choice back: the node is still an unexpanded entry of the set
+#pragma unroll
+        for (int s = 0; s < S; s++) ti[s] = ti[s] == (pre_id | kFDone) ? pre_id : ti[s];
+      }
+      const Near u = nearest();
+      const bool any = u.any;
+      need_heap = ghost_key == lb;
+      if (any) {
+        need_heap = u.same > 1 || (need_heap && u.key == lb);
+        next_id = u.id;
+      } else if (!need_heap) {
+        break;   // nothing left that the reference could pop with dist <= lowerBound
+      }
     if (__builtin_expect(need_heap, 0)) {
       // ---- bring the heap up to date and pop its root (a real call: the replay keeps its own registers, see flat_heap_sync) ----
 #ifdef HS_FLAT_DIAG
@@ -650,13 +686,19 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
       if (fo.stop) break;
       next_id = fo.next_id;
     }
-    // flag the node expanded where it sits in the result set
+      // flag the node expanded where it sits in the result set
 #pragma unroll
-    for (int s = 0; s < S; s++) ti[s] = ti[s] == next_id ? (next_id | kFDone) : ti[s];
-
-    // ---- expand it: its level-0 list is one aligned tile (:358-369) ---------------------------------------------------
-    uint32_t id = kNone;
-    if ((uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
+      for (int s = 0; s < S; s++) ti[s] = ti[s] == next_id ? (next_id | kFDone) : ti[s];
+      // ---- its level-0 list is one aligned tile (:358-369)
+      if ((uint32_t)lane < stride) id = ix.tile0[(size_t)next_id * stride + lane];
+    }
+#ifdef HS_FLAT_DIAG
+    diag_pre += have_pre ? 1u : 0u;
+    HS_DIAG_LAP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HS_DIAG_LAP(1);
+#endif
+    have_pre = false;
     n_hops++;
     const bool valid = id != kNone;
     const uint32_t m = __popcll(hs_ballot(valid));
@@ -668,6 +710,7 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
     n_dist += cnt;
     if (isnew) nid[__popcll(nm & ((1ull << lane) - 1ull))] = id;   // unvisited ids, adjacency order
     wave_sync();
+    HS_DIAG_LAP(2);
     uint32_t n_acc_hop = 0;
     for (uint32_t base = 0; base < cnt; base += 8) {
       const uint32_t j = base + grp;
@@ -675,6 +718,43 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
       const uint32_t rid = nid[act ? j : base];   // idle groups re-read the pass's first row (cache hit) and discard
       const float d = flat_dist8<METRIC, D16>(ix.vec, dim, qv, rid, s8);   // :395-396
       const int my_key = (s8 == OWN && act) ? dkey<METRIC>(d) : kFKeyInf;
+#ifdef HS_FLAT_DIAG
+      asm volatile("s_nop 0" : : "v"(my_key) : "memory");
+      HS_DIAG_LAP(3);
+#endif
+      // ---- the next node, before the accept pass (last pass of the hop): candidate_set's minimum once this hop's pushes are in
+      // is the nearest unexpanded entry u of the set as it stands, or the nearest new neighbour b if that one is accepted --
+      // it is iff it passes the bound as it stands now: earlier neighbours of the pass are strictly farther and cannot take
+      // the bound down to it -- and strictly nearer than u.  u must still be in the set afterwards: at most the new keys below
+      // u's move it up.  Ties (b's key twice, b == u, u's key twice) and a ghost at the bound are left to the top of the loop.
+      int b_lane = -1;
+      if (base + 8 >= cnt && ghost_key != lb) {
+        const Near u = nearest();
+        int mk = min(my_key, __builtin_amdgcn_update_dpp(kFKeyInf, my_key, 0x118, 0xf, 0xf, false));   // row_shr:8: owner lanes 8 apart
+        const int b_key = min(min(__builtin_amdgcn_readlane(mk, OWN + 8), __builtin_amdgcn_readlane(mk, OWN + 24)),
+                              min(__builtin_amdgcn_readlane(mk, OWN + 40), __builtin_amdgcn_readlane(mk, OWN + 56)));
+        const bool b_ok = b_key < lb;
+        if (b_ok && (!u.any || b_key < u.key)) {
+          const unsigned long long bm = hs_ballot(my_key == b_key);
+          if (__popcll(bm) == 1) {
+            b_lane = __ffsll((long long)bm) - 1;
+            have_pre = true;
+            pre_key = b_key;
+            pre_id = __builtin_amdgcn_readlane(rid, b_lane);
+          }
+        } else if (u.any && u.same == 1 && (!b_ok || u.key < b_key)) {
+          const uint32_t below = __popcll(hs_ballot(my_key < u.key));
+          if ((uint32_t)(u.p * S + u.slot) + below < ef) {
+            have_pre = true;
+            pre_key = u.key;
+            pre_id = u.id;
+#pragma unroll
+            for (int s = 0; s < S; s++) ti[s] = ti[s] == pre_id ? (pre_id | kFDone) : ti[s];
+          }
+        }
+        pre_tile = kNone;
+        if (have_pre && (uint32_t)lane < stride) pre_tile = ix.tile0[(size_t)pre_id * stride + lane];
+      }
       // ---- accept (:403-452), adjacency order (= lane order of the owner lanes).  lowerBound only falls.
       unsigned long long todo = hs_ballot(my_key < lb);
       unsigned long long am = 0;
@@ -683,13 +763,16 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
         todo &= todo - 1;
         const int kj = __builtin_amdgcn_readlane(my_key, jl);
         if (kj < lb) {
-          const uint32_t idj = __builtin_amdgcn_readlane(rid, jl);
+          const uint32_t idj = __builtin_amdgcn_readlane(rid, jl) | (jl == b_lane ? kFDone : 0u);   // (the chosen one enters flagged)
           am |= 1ull << jl;
           uint32_t pos = 0;   // entries with key <= kj stay in front
 #pragma unroll
           for (int s = 0; s < S; s++) pos += __popcll(hs_ballot(tk[s] <= kj));
-          const int ek = lb;                                   // the entry this insertion pushes beyond rank ef-1
-          const uint32_t ei = rank_id<S>(ti, ef - 1);
+          // without spare ranks behind ef - 1 the entry this insertion pushes out is gone at once: look at it now
+          // (with spare ranks the evicted entries stay in the array and are looked at once per hop, below)
+          const int ek = lb;
+          uint32_t ei = 0;
+          if (exact_fit) ei = rank_id<S>(ti, ef - 1);
           const int upk = __builtin_amdgcn_update_dpp(0, tk[S - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
           const uint32_t upi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ti[S - 1], 0x138, 0xf, 0xf, false);
 #pragma unroll
@@ -703,14 +786,17 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
             tk[0] = gt ? upk : tk[0];
             ti[0] = gt ? upi : ti[0];
           }
+          {   // the new entry: one v_writelane per register, in the slot the rank falls in
+            const uint32_t pl = pos / S, ps = pos % S;
 #pragma unroll
-          for (int s = 0; s < S; s++) {
-            const bool eq = (uint32_t)(laneS + s) == pos;
-            tk[s] = eq ? kj : tk[s];
-            ti[s] = eq ? idj : ti[s];
+            for (int s = 0; s < S; s++)
+              if (ps == (uint32_t)s) {
+                tk[s] = (int)write_lane((uint32_t)tk[s], (uint32_t)kj, pl);
+                ti[s] = write_lane(ti[s], idj, pl);
+              }
           }
           lb = rank_key<S>(tk, ef - 1);   // :450-452
-          if (ek != kFKeyInf && lb == ek) {   // an entry left the set at exactly the new bound
+          if (exact_fit && ek != kFKeyInf && lb == ek) {   // an entry left the set at exactly the new bound
             btie = true;
             if ((int)ei >= 0) ghost_key = ek;   // ... unexpanded: the reference may still pop it
           }
@@ -724,6 +810,22 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
         n_log += na;
         n_acc_hop += na;
       }
+      HS_DIAG_LAP(4);
+    }
+    if (!exact_fit && n_acc_hop != 0 && lb != kFKeyInf) {
+      // entries evicted at exactly the bound sit right behind rank ef - 1 for as long as the bound does not move: one of them
+      // decides the answer when ef == k (btie), an unexpanded one is still a candidate of the reference (ghost)
+      unsigned long long eq = 0, un = 0;
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        const unsigned long long e = hs_ballot(tk[s] == lb) & ~inr[s];
+        eq |= e;
+        un |= e & hs_ballot((int)ti[s] >= 0);
+      }
+      if (eq) btie = true;
+      if (un) ghost_key = lb;
+      // (an array whose very last entry still has the bound's key may have lost such an entry off its end)
+      if (__builtin_expect(rank_key<S>(tk, 64 * S - 1) == lb, 0)) { rc = 3; break; }
     }
     hl = write_lane(hl, uni(n_acc_hop), uni(hop0 & 63u));
     hop0++;
@@ -732,6 +834,7 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
       hoplog[hop0 - 64 + lane] = hl;
     }
     if (__builtin_expect(n_log > a.log_cap, 0)) { rc = 3; break; }
+    HS_DIAG_LAP(5);
   }
   if (__builtin_expect(rc == 1 || rc == 2, 0)) {
     flag_query(a, qi, ST_OVERFLOW, rc - 1, lane);
@@ -804,9 +907,11 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
       a.stats[qi * 4 + 2] = n_nbr;
       a.stats[qi * 4 + 3] = replay ? 1u : a.pass_id;
 #ifdef HS_FLAT_DIAG
-      uint32_t *dg = a.stats + (size_t)a.nq * 4 + qi * 8;
+      uint32_t *dg = a.stats + (size_t)a.nq * 4 + qi * 16;
       dg[4] = (uint32_t)diag_t0;                                          // start, 100 MHz ticks (low word)
       dg[5] = diag_sync_ticks;                                            // ticks spent inside heap replays
+      dg[6] = diag_pre;                                                   // hops whose node was chosen before the accept pass
+      for (int i = 0; i < 6; i++) dg[8 + i] = diag_ph[i];
       dg[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0);   // 100 MHz ticks
       dg[1] = diag_syncs;
       dg[2] = diag_replayed;

@@ -98,10 +98,11 @@ def load_product():
 class Oracle:
     """ctypes view of oracle/liboracle.so (CPU restatement; checker only)."""
 
-    def __init__(self):
-        so = os.path.join(ROOT, "oracle", "liboracle.so")
+    def __init__(self, variant=""):
+        """variant "": the pinned parity build; "_ofast": the reference's own -Ofast flags (timing only, bench.py)."""
+        so = os.path.join(ROOT, "oracle", f"liboracle{variant}.so")
         if not os.path.exists(so):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), f"liboracle{variant}.so"])
         L = ctypes.CDLL(so)
         L.hso_last_error.restype = ctypes.c_char_p
         L.hso_load.restype = ctypes.c_void_p

@@ -156,12 +156,11 @@ def test_two_rank_processes_drive_the_device_entry(hs, slim_file, tmp_path, nq):
     assert open(res).read() == "OK"
 
 
-def test_group_kernel_parity_under_env(hs, tmp_path):
-    """The four-queries-per-wavefront kernel (group_search.hip; HS_GROUP=1, off by default because it measured slower) and the lean
-    kernel (lean_search.hip; serves ef >= 192 by default, forced for every ef here):
-    same labels, distances and counters as the fast kernel on tie-heavy integer data and on a tie-free graph, with
-    starved scratch (tier-2 visited set / candidate heap) as well; likewise the ordered three-launch pass and the 32-bit form of
-    the visited set, each forced by its environment knob."""
+def test_kernel_variants_parity_under_env(hs, tmp_path):
+    """The flat kernel (flat_search.hip: the default on every index it supports -- lazily replayed candidate heap, bucketed visited
+    set) and the lean kernel (lean_search.hip, forced for every ef here): same labels, distances and counters as the fast kernel
+    on tie-heavy integer data, with starved scratch (overflow list / tier-2 visited set / candidate heap) as well; likewise the
+    ordered three-launch pass and the 32-bit form of the visited set, each forced by its environment knob."""
     code = r'''
 import os, sys, numpy as np
 sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
@@ -185,7 +184,8 @@ np.savez(sys.argv[3], **out)
     hs.convert_slim(str(tmp_path / "h.bin"), str(tmp_path / "s.bin"), 128, threads=8)
     res = {}
     # (the last two force the descent / order / level-0 launches of large batches, csrc/capi.cpp, onto this 300-query batch)
-    for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "0"}), ("group", {"HS_GROUP": "1"}), ("lean", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "0"}),
+    for tag, env in (("fast", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "0"}), ("flat", {"HS_KERNEL": "flat", "HS_ORDER": "0"}), ("flat_ordered", {"HS_KERNEL": "flat", "HS_ORDER": "1"}),
+                     ("lean", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "0"}),
                      ("fast_ordered", {"HS_LEAN_MIN_EF": "100000", "HS_ORDER": "1"}), ("lean_ordered", {"HS_LEAN_MIN_EF": "1", "HS_ORDER": "1"}),
                      # the visited set's 32-bit form (what an index beyond 2^(log2(buckets)+16) nodes gets) instead of the 16-bit one
                      ("fast_vis32", {"HS_LEAN_MIN_EF": "100000", "HS_VIS16": "0"}), ("lean_vis32", {"HS_LEAN_MIN_EF": "1", "HS_VIS16": "0"}),
@@ -195,7 +195,8 @@ np.savez(sys.argv[3], **out)
         subprocess.check_call([sys.executable, wf, ROOT, str(tmp_path), of], env=dict(os.environ, **env))
         res[tag] = np.load(of)
     for key in res["fast"].files:
-        assert np.array_equal(res["fast"][key], res["group"][key]), key
+        assert np.array_equal(res["fast"][key], res["flat"][key]), key
+        assert np.array_equal(res["fast"][key], res["flat_ordered"][key]), key
         assert np.array_equal(res["fast"][key], res["lean"][key]), key
         assert np.array_equal(res["fast"][key], res["fast_ordered"][key]), key
         assert np.array_equal(res["fast"][key], res["lean_ordered"][key]), key

@@ -416,7 +416,7 @@ def test_ordered_two_launch_pass(hs, oracle, tmp_path, metric, dim):
     """From 6144 queries per launch the fast / lean pass runs as three launches -- upper-level descent, queries ordered by
     the distance of their level-0 entry, level-0 search in that order: same answers and counters as the one-launch pass,
     for both index kinds, the (q,k) overloads that tag the enter point and a large ef (the lean kernel under this order:
-    test_group_kernel_parity_under_env)."""
+    test_kernel_variants_parity_under_env)."""
     base = mixture(6000, dim, 91)
     q = mixture(7000, dim, 92)
     hp, sp = str(tmp_path / "h.bin"), str(tmp_path / "s.bin")

@@ -27,7 +27,7 @@ ix = hs.Index(os.path.join(idir, "slim.bin"), hs.HS_KIND_SLIM, D)
 q_t = torch.from_numpy(headline_data(NQ, D, 456)).to(dev)
 lab = torch.empty((NQ, K), dtype=torch.int32, device=dev)
 cnt = torch.empty((NQ,), dtype=torch.int32, device=dev)
-stats = torch.zeros((3 * NQ, 4), dtype=torch.int32, device=dev)
+stats = torch.zeros((5 * NQ, 4), dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for ef in efs:
     ix.set_ef(ef)
@@ -40,7 +40,7 @@ for ef in efs:
     e1.record()
     torch.cuda.synchronize()
     h = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    s4, dg = h[:NQ], h[NQ:].reshape(NQ, 8)
+    s4, dg = h[:NQ], h[NQ:].reshape(NQ, 16)
     wall = dg[:, 0] / 100.0   # us
     hops, rep = s4[:, 1], dg[:, 2]
     c_tie, c_ghost, c_end = dg[:, 1] & 0xFF, (dg[:, 1] >> 8) & 0xFF, dg[:, 1] >> 16
@@ -59,5 +59,16 @@ for ef in efs:
     sync_us = dg[:, 5] / 100.0
     print(f"   replay: {sync_us[syncs > 0].mean() if (syncs > 0).any() else 0:.0f} us per synced query = {sync_us.sum() / max(rep.sum(), 1):.2f} us per replayed hop; kernel span {end.max():.0f} us, "
           f"last starts at {t0.max() / 100.0:.0f} us; the 5 last to finish: " + "; ".join(f"start {t0[i] / 100.0:.0f} wall {wall[i]:.0f} (replay {sync_us[i]:.0f}) hops {hops[i]}" for i in np.argsort(-end)[:5]))
+    ph = dg[:, 8:14].astype(np.float64)
+    l0 = np.maximum(hops - s4[:, 1].min() * 0, 1)
+    names = ["select", "tile wait", "visited+compaction", "rows+distances", "accept(+pre-select)", "hop end"]
+    print("   shader cycles per hop (level-0 hops ~ all hops; the stamps themselves cost ~10 %): " + ", ".join(f"{n} {ph[:, i].sum() / hops.sum():.0f}" for i, n in enumerate(names))
+          + f"; sum {ph.sum() / hops.sum():.0f}; hops pre-selected {dg[:, 6].sum() / hops.sum() * 100:.0f}%")
+    ns = syncs == 0
+    for lo, hi in ((0, 0), (1, 8), (9, 32), (33, 64)):
+        m = ns & (ovf >= lo) & (ovf <= hi)
+        if m.any():
+            print(f"   no-sync queries with {lo}..{hi} ids in the overflow list: {m.sum()} queries, {wall[m].sum() / hops[m].sum():.2f} us/hop, hops mean {hops[m].mean():.0f}, n_dist/hop {s4[m, 0].sum() / hops[m].sum():.2f}")
+    print("   last to finish, detail: " + "; ".join(f"[start {t0[i] / 100.0:.0f} wall {wall[i]:.0f} replay {sync_us[i]:.0f} hops {hops[i]} n_dist {s4[i, 0]} ovf {ovf[i]} t2 {n2[i]}]" for i in np.argsort(-end)[:6]))
     top = np.argsort(-wall)[:8]
     print("   slowest: " + "; ".join(f"{wall[i]:.0f}us hops={hops[i]} syncs={syncs[i]} rep={rep[i]} ovf={ovf[i]} t2={n2[i]}" for i in top), flush=True)
