@@ -90,6 +90,9 @@ def lib():
     L.hs_comm_free.argtypes = [vp]
     L.hs_comm_size.argtypes = [vp]
     L.hs_search_batch_sharded.argtypes = [vp, vp, vp, sz, sz, ci, vp, vp, vp, vp]
+    L.hs_search_batch_sharded_async.argtypes = [vp, vp, vp, sz, sz, ci, vp, vp, vp, vp, ci]
+    L.hs_comm_check.argtypes = [vp, vp, ci]
+    L.hs_comm_slots.argtypes = [vp]
     L.hs_comm_results_dev.argtypes = [vp, ci, vp, vp, vp, vp]
     L.hs_search_batch_raw.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp]
     L.hs_search_batch_filtered.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
@@ -286,6 +289,19 @@ class Comm:
                                              dists.ctypes.data if want_dists else None, cnt.ctypes.data))
         return dict(labels=labels, dists=dists, cnt=cnt)
 
+    def slots(self):
+        return lib().hs_comm_slots(self._h)
+
+    def search_ids_async(self, replicas, q_pinned, k, labels_pinned, slot):
+        """hs_search_batch_sharded_async, HS_MODE_SLIM_IDS: numpy views of page-locked memory; pair with check(replicas, slot)."""
+        hs_ = (ctypes.c_void_p * len(replicas))(*[r._h for r in replicas])
+        _check(lib().hs_search_batch_sharded_async(self._h, hs_, q_pinned.ctypes.data, q_pinned.shape[0], k, HS_MODE_SLIM_IDS,
+                                                   labels_pinned.ctypes.data, None, None, None, slot))
+
+    def check(self, replicas, slot):
+        hs_ = (ctypes.c_void_p * len(replicas))(*[r._h for r in replicas])
+        _check(lib().hs_comm_check(self._h, hs_, slot))
+
     def search_pq(self, replicas, queries, k):
         q = np.ascontiguousarray(queries, np.float32)
         nq = q.shape[0]
@@ -329,6 +345,21 @@ class Index:
         _check(lib().hs_index_from_host_arrays(kind, metric, n, dim, v.ctypes.data, None if lab is None else lab.ctypes.data,
                                                None if dl is None else dl.ctypes.data, lv.ctypes.data, ptr.ctypes.data, ids.ctypes.data,
                                                int(enterpoint), int(maxlevel), int(threshold_level), device, ctypes.byref(self._h)))
+        return self
+
+    @classmethod
+    def from_csr(cls, kind, metric, vectors, levels, list_ptr, list_ids, enterpoint, maxlevel, labels=None, threshold_level=0, device=0):
+        """hs_index_from_host_arrays with the flat arrays as the C ABI takes them (node i owns levels[i] + 1 consecutive lists)."""
+        v = np.ascontiguousarray(vectors, np.float32)
+        n, dim = v.shape
+        lv, ptr, ids = np.ascontiguousarray(levels, np.int32), np.ascontiguousarray(list_ptr, np.uint64), np.ascontiguousarray(list_ids, np.uint32)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint64)
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.kind, self.dim, self.metric, self.device, self.ef = kind, dim, metric, device, 10
+        _check(lib().hs_index_from_host_arrays(kind, metric, n, dim, v.ctypes.data, None if lab is None else lab.ctypes.data, None,
+                                               lv.ctypes.data, ptr.ctypes.data, ids.ctypes.data, int(enterpoint), int(maxlevel),
+                                               int(threshold_level), device, ctypes.byref(self._h)))
         return self
 
     def close(self):

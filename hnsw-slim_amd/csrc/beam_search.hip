@@ -1189,7 +1189,8 @@ static hipError_t launch(K kern, const DevIndex &ix, const SearchArgs &a, size_t
 // One workgroup: min / max of the entry distances, a 4096-bin histogram over that range (farthest first), its prefix
 // sums, then each query takes the next free position of its bin.  Order inside a bin is whatever the atomics give: the
 // order only decides when a query STARTS, never what it returns.
-constexpr uint32_t kOrderBins = 4096, kOrderThreads = 1024;
+// (256 threads: with several batches in flight this trivial kernel must not wait for sixteen free wave slots on one CU)
+constexpr uint32_t kOrderBins = 4096, kOrderThreads = 256, kOrderPer = kOrderBins / kOrderThreads;
 __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry, uint32_t *order, uint32_t nq) {
   __shared__ uint32_t bins[kOrderBins];
   __shared__ float red_lo[kOrderThreads / 64], red_hi[kOrderThreads / 64];
@@ -1218,9 +1219,9 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
   };
   for (uint32_t i = t; i < nq; i += kOrderThreads) atomicAdd(&bins[bin_of(key_of(i))], 1u);
   __syncthreads();
-  // exclusive prefix sums of the bins: four consecutive bins per thread, wave scan, then the wave totals
-  uint32_t v[4], sum = 0;
-  for (int j = 0; j < 4; j++) { v[j] = bins[4 * t + j]; sum += v[j]; }
+  // exclusive prefix sums of the bins: kOrderPer consecutive bins per thread, wave scan, then the wave totals
+  uint32_t v[kOrderPer], sum = 0;
+  for (uint32_t j = 0; j < kOrderPer; j++) { v[j] = bins[kOrderPer * t + j]; sum += v[j]; }
   uint32_t incl = sum;
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t up = __shfl_up(incl, off);
@@ -1232,12 +1233,12 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
   for (uint32_t w = 0; w < wv; w++) base += wave_tot[w];
   uint32_t run = base + incl - sum;
   __syncthreads();
-  for (int j = 0; j < 4; j++) { bins[4 * t + j] = run; run += v[j]; }
+  for (uint32_t j = 0; j < kOrderPer; j++) { bins[kOrderPer * t + j] = run; run += v[j]; }
   __syncthreads();
   for (uint32_t i = t; i < nq; i += kOrderThreads) order[atomicAdd(&bins[bin_of(key_of(i))], 1u)] = i;
 }
 hipError_t launch_order(const uint4 *entry, uint32_t *order, uint32_t nq, hipStream_t stream) {
-  static_assert(kOrderBins == 4 * kOrderThreads, "four bins per thread in the prefix step");
+  static_assert(kOrderBins == kOrderPer * kOrderThreads, "whole bins per thread in the prefix step");
   if (nq == 0) return hipSuccess;
   hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, entry, order, nq);
   return hipGetLastError();

@@ -143,6 +143,7 @@ struct Shape {
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
+static constexpr size_t kFallbackLds = 64 * 1024;   // LDS of the last-resort pass (strict kernel)
 static constexpr uint32_t kLeanMinEfContinuous = 192;   // continuous data: the fast kernel's flat start never materialises a heap and wins below this
 static constexpr uint32_t kLeanMinEf = 64;    // from here upwards the lean kernel (keys-only result set, 95 VGPRs: 5 waves per SIMD without scratch, smaller LDS share)
                                               // is the faster one on its shapes (L2, d = 96 / 128): ef=70 -5 % single launch / +4 % on a 32k call (0.41 of the HBM peak),
@@ -199,14 +200,21 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.cand_cap > 128) s.cand_cap = (s.cand_cap / 2 + 1) & ~1u;
   if (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU)
     return fail(HS_ERR_CAPACITY, "ef/dim do not fit the 160 KiB LDS of one CU");
-  // last resort: the largest power-of-two hash that leaves at least as many bytes to the candidate heap
+  // last resort: the largest power-of-two hash that leaves at least as many bytes to the candidate heap, within kFallbackLds.
+  // (Not the whole CU: this pass is launched with every batch and is normally empty -- a workgroup that asks for all 160 KiB
+  // waits until a CU has drained completely, which with several batches in flight held every batch's stream for ~0.5 ms,
+  // profiles/r03_kernel_stats_pipelined.csv; beyond its LDS share the pass continues in the tier-2 regions like every other.)
   const size_t fixed = strict_lds_bytes(dim, s.ef, 0, 0);
-  size_t rem = kLdsPerCU - fixed;
-  uint32_t hs_slots = 256;
-  while ((size_t)hs_slots * 2 * 4 <= rem / 2) hs_slots *= 2;
-  s.fb_hash_slots = std::max(hs_slots, s.hash_slots);
-  size_t cand_bytes = kLdsPerCU - fixed - (size_t)s.fb_hash_slots * 4;
-  s.fb_cand_cap = (uint32_t)((cand_bytes / 8) & ~size_t(1));
+  for (size_t fb_total : {std::min<size_t>(kLdsPerCU, std::max<size_t>(kFallbackLds, fixed + 16 * 1024)), kLdsPerCU}) {
+    const size_t rem = fb_total - fixed;
+    uint32_t hs_slots = 256;
+    while ((size_t)hs_slots * 2 * 4 <= rem / 2) hs_slots *= 2;
+    s.fb_hash_slots = std::max(hs_slots, s.hash_slots);
+    if (fixed + (size_t)s.fb_hash_slots * 4 + 1024 > fb_total) continue;   // (a first-pass hash larger than this share: whole CU)
+    const size_t cand_bytes = fb_total - fixed - (size_t)s.fb_hash_slots * 4;
+    s.fb_cand_cap = (uint32_t)((cand_bytes / 8) & ~size_t(1));
+    break;
+  }
   if (s.fb_cand_cap < s.cand_cap) { s.fb_cand_cap = s.cand_cap; s.fb_hash_slots = s.hash_slots; }
   return HS_OK;
 }
@@ -1408,21 +1416,31 @@ hs_status hs_rabitq_estimate(size_t padded, const uint64_t *codes, const float *
 // One process drives n devices; every call below is asynchronous on a per-device stream, so a single host thread
 // enqueues the whole step (RCCL's single-process group API: ncclCommInitAll + ncclGroupStart/End).  RCCL is opened with
 // dlopen (RTLD_LOCAL): no link-time dependency, and a host process that already carries another RCCL build (PyTorch
-// bundles one) keeps its own symbols.
+// bundles one) keeps its own symbols.  A communicator has kCommSlots independent SLOTS (streams, events, gather buffers per
+// device): hs_search_batch_sharded_async(.., slot) only enqueues, hs_comm_check(.., slot) waits for that slot's batch, so a
+// caller keeps several batches in flight per device -- a split batch is a small launch per device and lasts as long as its
+// longest query, the chip only fills up with several of them.
+static constexpr int kCommSlots = 8;
 struct hs_comm {
   int n = 0;
   std::vector<int> dev;
   bool loopback = false;   // the same device listed more than once (1-GPU rehearsal): the gather runs as device copies
   void *lib = nullptr;
   std::vector<void *> comms;
-  std::vector<hipStream_t> streams;
-  std::vector<hipEvent_t> done;
   struct Dev {
     DevBuf<float> q, all_dist;
     DevBuf<uint32_t> all_l32, all_cnt;
     DevBuf<uint64_t> all_l64;
   };
-  std::vector<std::unique_ptr<Dev>> d;
+  struct Slot {
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    std::vector<std::unique_ptr<Dev>> d;
+    std::vector<size_t> rows;   // queries device r searched in the batch in flight (0: nothing to check)
+    bool busy = false;
+  };
+  std::vector<Slot> slots;
+  int last_slot = 0;
   int (*CommInitAll)(void **, int, const int *) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
@@ -1431,18 +1449,88 @@ struct hs_comm {
   const char *(*GetErrorString)(int) = nullptr;
 };
 enum { kNcclUint8 = 1, kNcclUint32 = 3, kNcclUint64 = 5, kNcclFloat32 = 7 };   // ncclDataType_t (rccl.h)
+#if __has_include(<rccl/rccl.h>)
+}  // extern "C"
+#include <rccl/rccl.h>   // declarations only (nothing here is called through them): the constants above against the header of this ROCm
+static_assert((int)ncclUint8 == kNcclUint8 && (int)ncclUint32 == kNcclUint32 && (int)ncclUint64 == kNcclUint64 && (int)ncclFloat32 == kNcclFloat32,
+              "ncclDataType_t values differ from the ones hs_search_batch_sharded passes to the dlopen'ed RCCL");
+extern "C" {
+#endif
 
 void hs_comm_free(hs_comm *c) {
   if (!c) return;
+  for (auto &sl : c->slots)
+    for (int r = 0; r < (int)c->dev.size(); r++) {
+      (void)hipSetDevice(c->dev[r]);
+      if (r < (int)sl.d.size()) sl.d[r].reset();
+      if (r < (int)sl.done.size() && sl.done[r]) (void)hipEventDestroy(sl.done[r]);
+      if (r < (int)sl.streams.size() && sl.streams[r]) (void)hipStreamDestroy(sl.streams[r]);
+    }
   for (int r = 0; r < (int)c->dev.size(); r++) {
     (void)hipSetDevice(c->dev[r]);
     if (r < (int)c->comms.size() && c->comms[r] && c->CommDestroy) c->CommDestroy(c->comms[r]);
-    if (r < (int)c->d.size()) c->d[r].reset();
-    if (r < (int)c->done.size() && c->done[r]) (void)hipEventDestroy(c->done[r]);
-    if (r < (int)c->streams.size() && c->streams[r]) (void)hipStreamDestroy(c->streams[r]);
   }
   if (c->lib) dlclose(c->lib);
   delete c;
+}
+
+static hs_status comm_slot_ready(hs_comm *c, int slot) {   // streams / events / buffers of a slot are created on first use
+  hs_comm::Slot &sl = c->slots[slot];
+  if (!sl.streams.empty()) return HS_OK;
+  sl.streams.assign(c->n, nullptr);
+  sl.done.assign(c->n, nullptr);
+  sl.rows.assign(c->n, 0);
+  for (int r = 0; r < c->n; r++) {
+    HIP_TRY(hipSetDevice(c->dev[r]));
+    HIP_TRY(hipStreamCreateWithFlags(&sl.streams[r], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&sl.done[r], hipEventDisableTiming));
+    sl.d.emplace_back(new hs_comm::Dev());
+  }
+  return HS_OK;
+}
+
+#define NCCL_TRY(c, expr)                                                                                  \
+  do {                                                                                                     \
+    const int _rc = (expr);                                                                                \
+    if (_rc != 0) return fail(HS_ERR_DEVICE, std::string(#expr ": ") + ((c)->GetErrorString ? (c)->GetErrorString(_rc) : "RCCL error")); \
+  } while (0)
+
+// The first real exchange of a communicator: 16 words per device through the same in-place all-gather the search uses, checked
+// on every device -- a wrong datatype constant, a mismatched library or a broken link shows here, not in a result array.
+static hs_status comm_selftest(hs_comm *c) {
+  const int n = c->n;
+  hs_status st = comm_slot_ready(c, 0);
+  if (st != HS_OK) return st;
+  hs_comm::Slot &sl = c->slots[0];
+  std::vector<uint32_t> h((size_t)n * 16);
+  for (int r = 0; r < n; r++) {
+    HIP_TRY(hipSetDevice(c->dev[r]));
+    HIP_TRY(sl.d[r]->all_l32.ensure((size_t)n * 16));
+    for (int i = 0; i < n * 16; i++) h[i] = (i / 16 == r) ? 0xA5000000u + (uint32_t)(r * 16 + i % 16) : 0u;
+    HIP_TRY(hipMemcpyAsync(sl.d[r]->all_l32.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, sl.streams[r]));
+    HIP_TRY(hipStreamSynchronize(sl.streams[r]));
+  }
+  int first_err = 0;
+  NCCL_TRY(c, c->GroupStart());
+  for (int r = 0; r < n; r++) {
+    const int rc = c->AllGather(sl.d[r]->all_l32.p + (size_t)r * 16, sl.d[r]->all_l32.p, 16, kNcclUint32, c->comms[r], sl.streams[r]);
+    if (rc != 0 && first_err == 0) first_err = rc;
+  }
+  const int rc_end = c->GroupEnd();
+  if (first_err == 0) first_err = rc_end;
+  for (int r = 0; r < n; r++) {
+    (void)hipSetDevice(c->dev[r]);
+    (void)hipStreamSynchronize(sl.streams[r]);
+  }
+  if (first_err != 0) return fail(HS_ERR_DEVICE, std::string("RCCL all-gather self-test: ") + (c->GetErrorString ? c->GetErrorString(first_err) : "error"));
+  for (int r = 0; r < n; r++) {
+    HIP_TRY(hipSetDevice(c->dev[r]));
+    HIP_TRY(hipMemcpy(h.data(), sl.d[r]->all_l32.p, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n * 16; i++)
+      if (h[i] != 0xA5000000u + (uint32_t)i)
+        return fail(HS_ERR_DEVICE, "RCCL all-gather self-test: device " + std::to_string(c->dev[r]) + " holds a wrong word at " + std::to_string(i));
+  }
+  return HS_OK;
 }
 
 hs_status hs_comm_init(int n_gpus, const int *devices, hs_comm **out) {
@@ -1457,14 +1545,9 @@ hs_status hs_comm_init(int n_gpus, const int *devices, hs_comm **out) {
     for (int t = 0; t < r; t++) c->loopback = c->loopback || c->dev[t] == d;
     c->dev.push_back(d);
   }
-  c->streams.assign(n_gpus, nullptr);
-  c->done.assign(n_gpus, nullptr);
-  for (int r = 0; r < n_gpus; r++) {
-    HIP_TRY(hipSetDevice(c->dev[r]));
-    HIP_TRY(hipStreamCreateWithFlags(&c->streams[r], hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->done[r], hipEventDisableTiming));
-    c->d.emplace_back(new hs_comm::Dev());
-  }
+  c->slots.resize(kCommSlots);
+  hs_status st = comm_slot_ready(c.get(), 0);
+  if (st != HS_OK) return st;
   if (n_gpus > 1 && !c->loopback) {
     c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -1480,24 +1563,45 @@ hs_status hs_comm_init(int n_gpus, const int *devices, hs_comm **out) {
     c->comms.assign(n_gpus, nullptr);
     const int rc = c->CommInitAll(c->comms.data(), n_gpus, c->dev.data());
     if (rc != 0) return fail(HS_ERR_DEVICE, std::string("ncclCommInitAll: ") + (c->GetErrorString ? c->GetErrorString(rc) : "error"));
+    st = comm_selftest(c.get());
+    if (st != HS_OK) return st;
   }
   *out = c.release();
   return HS_OK;
 }
 
 int hs_comm_size(const hs_comm *c) { return c ? c->n : 0; }
+int hs_comm_slots(const hs_comm *c) { return c ? (int)c->slots.size() : 0; }
 
-#define NCCL_TRY(c, expr)                                                                                  \
-  do {                                                                                                     \
-    const int _rc = (expr);                                                                                \
-    if (_rc != 0) return fail(HS_ERR_DEVICE, std::string(#expr ": ") + ((c)->GetErrorString ? (c)->GetErrorString(_rc) : "RCCL error")); \
-  } while (0)
+// Waits for the batch in flight in `slot` and reports its capacity errors (hs_search_check on every device that searched).
+hs_status hs_comm_check(hs_comm *c, hs_index *const *ixs, int slot) {
+  if (!c || !ixs || slot < 0 || slot >= (int)c->slots.size()) return fail(HS_ERR_INVALID, "bad argument");
+  hs_comm::Slot &sl = c->slots[slot];
+  if (!sl.busy) return HS_OK;
+  sl.busy = false;
+  hs_status worst = HS_OK;
+  std::string msg;
+  for (int r = 0; r < c->n; r++) {
+    if (!ixs[r]) return fail(HS_ERR_INVALID, "null index replica");
+    hs_status s = HS_OK;
+    if (sl.rows[r]) {
+      s = hs_search_check(ixs[r], sl.streams[r]);   // synchronises the stream, reads and clears its counters
+    } else {   // nothing was searched on this device in this batch: only the exchange and the copies ran on its stream
+      if (hipSetDevice(c->dev[r]) != hipSuccess || hipStreamSynchronize(sl.streams[r]) != hipSuccess) s = fail(HS_ERR_DEVICE, "hipStreamSynchronize failed");
+    }
+    if (s != HS_OK && worst == HS_OK) { worst = s; msg = g_err; }
+  }
+  if (worst != HS_OK) return fail(worst, msg);
+  return HS_OK;
+}
 
 // Shard r = rows [r * S, min(nq, (r + 1) * S)), S = ceil(nq / n): device r searches its shard straight into slot r of
 // its [n * S x k] gather buffers, the in-place all-gather completes the other slots, device 0's copy goes to the host.
-hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
-                                  uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts) {
+// Enqueue only: queries and outputs (page-locked memory if the copies are to overlap) must stay valid until hs_comm_check(slot).
+hs_status hs_search_batch_sharded_async(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
+                                        uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts, int slot) {
   if (!c || !ixs || !queries) return fail(HS_ERR_INVALID, "null argument");
+  if (slot < 0 || slot >= (int)c->slots.size()) return fail(HS_ERR_INVALID, "bad slot");
   if (mode == HS_MODE_SLIM_IDS && !out_labels32) return fail(HS_ERR_INVALID, "out_labels32 required");
   if (mode == HS_MODE_PQ && (!out_labels64 || !out_dists || !out_counts)) return fail(HS_ERR_INVALID, "out_labels64/out_dists/out_counts required");
   if (mode != HS_MODE_SLIM_IDS && mode != HS_MODE_PQ) return fail(HS_ERR_INVALID, "bad mode");
@@ -1509,23 +1613,30 @@ hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float 
     if (ixs[r]->info.n != ixs[0]->info.n || ixs[r]->info.dim != ixs[0]->info.dim || ixs[r]->info.kind != ixs[0]->info.kind)
       return fail(HS_ERR_INVALID, "replicas differ");
   }
+  if (c->slots[slot].busy) return fail(HS_ERR_INVALID, "slot " + std::to_string(slot) + " still holds a batch: hs_comm_check it first");
   if (nq == 0) return HS_OK;
+  hs_status rs = comm_slot_ready(c, slot);
+  if (rs != HS_OK) return rs;
+  hs_comm::Slot &sl = c->slots[slot];
+  c->last_slot = slot;
   const size_t dim = ixs[0]->info.dim, S = (nq + n - 1) / n;
   const bool ids = mode == HS_MODE_SLIM_IDS;
   const bool want_d = out_dists != nullptr, want_c = out_counts != nullptr || !ids;
   for (int r = 0; r < n; r++) {
     HIP_TRY(hipSetDevice(c->dev[r]));
-    hs_comm::Dev &d = *c->d[r];
+    hs_comm::Dev &d = *sl.d[r];
     HIP_TRY(d.q.ensure(S * dim));
     if (ids) HIP_TRY(d.all_l32.ensure((size_t)n * S * k));
     else HIP_TRY(d.all_l64.ensure((size_t)n * S * k));
     if (want_d || !ids) HIP_TRY(d.all_dist.ensure((size_t)n * S * k));
     HIP_TRY(d.all_cnt.ensure((size_t)n * S));
     const size_t lo = std::min(nq, (size_t)r * S), m = std::min(nq, lo + S) - lo;
-    hipStream_t st = c->streams[r];
+    sl.rows[r] = m;
+    hipStream_t st = sl.streams[r];
     if (m < S) {   // a short (or empty) last shard: its padding rows must not be garbage in the gathered arrays
       if (ids) HIP_TRY(hipMemsetAsync(d.all_l32.p + (size_t)r * S * k, 0xFF, S * k * 4, st));
       else HIP_TRY(hipMemsetAsync(d.all_l64.p + (size_t)r * S * k, 0xFF, S * k * 8, st));
+      if (want_d || !ids) HIP_TRY(hipMemsetAsync(d.all_dist.p + (size_t)r * S * k, 0x7F, S * k * 4, st));   // 0x7F7F7F7F: a large finite float
       HIP_TRY(hipMemsetAsync(d.all_cnt.p + (size_t)r * S, 0, S * 4, st));
     }
     if (m) {
@@ -1535,29 +1646,44 @@ hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float 
                                d.all_cnt.p + (size_t)r * S, nullptr, nullptr, nullptr, st);
       if (s != HS_OK) return s;
     }
-    if (c->loopback) HIP_TRY(hipEventRecord(c->done[r], st));
+    if (c->loopback) HIP_TRY(hipEventRecord(sl.done[r], st));
   }
+  sl.busy = true;
   if (n > 1 && !c->loopback) {
+    // (an error inside the group must not leave it open: every call is made, the first error is reported after GroupEnd)
+    int first_err = 0;
     NCCL_TRY(c, c->GroupStart());
+    auto ag = [&](const void *src, void *dst, size_t cnt, int ty, int r) {
+      const int rc = c->AllGather(src, dst, cnt, ty, c->comms[r], sl.streams[r]);
+      if (rc != 0 && first_err == 0) first_err = rc;
+    };
     for (int r = 0; r < n; r++) {
-      hs_comm::Dev &d = *c->d[r];
-      hipStream_t st = c->streams[r];
-      if (ids) NCCL_TRY(c, c->AllGather(d.all_l32.p + (size_t)r * S * k, d.all_l32.p, S * k, kNcclUint32, c->comms[r], st));
-      else NCCL_TRY(c, c->AllGather(d.all_l64.p + (size_t)r * S * k, d.all_l64.p, S * k, kNcclUint64, c->comms[r], st));
-      if (want_d || !ids) NCCL_TRY(c, c->AllGather(d.all_dist.p + (size_t)r * S * k, d.all_dist.p, S * k, kNcclFloat32, c->comms[r], st));
-      if (want_c) NCCL_TRY(c, c->AllGather(d.all_cnt.p + (size_t)r * S, d.all_cnt.p, S, kNcclUint32, c->comms[r], st));
+      hs_comm::Dev &d = *sl.d[r];
+      if (ids) ag(d.all_l32.p + (size_t)r * S * k, d.all_l32.p, S * k, kNcclUint32, r);
+      else ag(d.all_l64.p + (size_t)r * S * k, d.all_l64.p, S * k, kNcclUint64, r);
+      if (want_d || !ids) ag(d.all_dist.p + (size_t)r * S * k, d.all_dist.p, S * k, kNcclFloat32, r);
+      if (want_c) ag(d.all_cnt.p + (size_t)r * S, d.all_cnt.p, S, kNcclUint32, r);
     }
-    NCCL_TRY(c, c->GroupEnd());
+    const int rc_end = c->GroupEnd();
+    if (first_err == 0) first_err = rc_end;
+    if (first_err != 0) {
+      for (int r = 0; r < n; r++) {
+        (void)hipSetDevice(c->dev[r]);
+        (void)hipStreamSynchronize(sl.streams[r]);
+      }
+      sl.busy = false;
+      return fail(HS_ERR_DEVICE, std::string("ncclAllGather: ") + (c->GetErrorString ? c->GetErrorString(first_err) : "RCCL error"));
+    }
   } else if (n > 1) {
     // rehearsal on one device: the same exchange as stream-ordered device copies (slot s of every rank <- slot s of rank s)
     for (int r = 0; r < n; r++) {
       HIP_TRY(hipSetDevice(c->dev[r]));
-      hs_comm::Dev &d = *c->d[r];
-      hipStream_t st = c->streams[r];
+      hs_comm::Dev &d = *sl.d[r];
+      hipStream_t st = sl.streams[r];
       for (int s2 = 0; s2 < n; s2++) {
         if (s2 == r) continue;
-        hs_comm::Dev &o = *c->d[s2];
-        HIP_TRY(hipStreamWaitEvent(st, c->done[s2], 0));
+        hs_comm::Dev &o = *sl.d[s2];
+        HIP_TRY(hipStreamWaitEvent(st, sl.done[s2], 0));
         if (ids) HIP_TRY(hipMemcpyAsync(d.all_l32.p + (size_t)s2 * S * k, o.all_l32.p + (size_t)s2 * S * k, S * k * 4, hipMemcpyDeviceToDevice, st));
         else HIP_TRY(hipMemcpyAsync(d.all_l64.p + (size_t)s2 * S * k, o.all_l64.p + (size_t)s2 * S * k, S * k * 8, hipMemcpyDeviceToDevice, st));
         if (want_d || !ids) HIP_TRY(hipMemcpyAsync(d.all_dist.p + (size_t)s2 * S * k, o.all_dist.p + (size_t)s2 * S * k, S * k * 4, hipMemcpyDeviceToDevice, st));
@@ -1568,28 +1694,29 @@ hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float 
   // the host takes the first nq rows of device 0's gathered arrays
   {
     HIP_TRY(hipSetDevice(c->dev[0]));
-    hs_comm::Dev &d = *c->d[0];
-    hipStream_t st = c->streams[0];
+    hs_comm::Dev &d = *sl.d[0];
+    hipStream_t st = sl.streams[0];
     if (out_labels32) HIP_TRY(hipMemcpyAsync(out_labels32, d.all_l32.p, nq * k * 4, hipMemcpyDeviceToHost, st));
     if (out_labels64) HIP_TRY(hipMemcpyAsync(out_labels64, d.all_l64.p, nq * k * 8, hipMemcpyDeviceToHost, st));
     if (out_dists) HIP_TRY(hipMemcpyAsync(out_dists, d.all_dist.p, nq * k * 4, hipMemcpyDeviceToHost, st));
     if (out_counts) HIP_TRY(hipMemcpyAsync(out_counts, d.all_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
   }
-  hs_status worst = HS_OK;
-  std::string msg;
-  for (int r = 0; r < n; r++) {   // synchronises every device's stream and reports capacity errors
-    hs_status s = hs_search_check(ixs[r], c->streams[r]);
-    if (s != HS_OK && worst == HS_OK) { worst = s; msg = g_err; }
-  }
-  if (worst != HS_OK) return fail(worst, msg);
   return HS_OK;
 }
-// The gathered result arrays as device `rank` holds them after hs_search_batch_sharded ([n * ceil(nq / n) x k], valid until
-// the next call): every device has the whole batch's top-k, e.g. for a re-ranking stage that runs on all of them.
+// The synchronous form: slot 0, enqueue + wait.
+hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
+                                  uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts) {
+  hs_status s = hs_search_batch_sharded_async(c, ixs, queries, nq, k, mode, out_labels32, out_labels64, out_dists, out_counts, 0);
+  if (s != HS_OK) return s;
+  return hs_comm_check(c, ixs, 0);
+}
+// The gathered result arrays as device `rank` holds them after the most recent sharded call ([n * ceil(nq / n) x k], valid until
+// that slot's next call): every device has the whole batch's top-k, e.g. for a re-ranking stage that runs on all of them.
 hs_status hs_comm_results_dev(hs_comm *c, int rank, const uint32_t **d_labels32, const uint64_t **d_labels64, const float **d_dists,
                               const uint32_t **d_counts) {
   if (!c || rank < 0 || rank >= c->n) return fail(HS_ERR_INVALID, "bad argument");
-  hs_comm::Dev &d = *c->d[rank];
+  if (c->slots[c->last_slot].d.empty()) return fail(HS_ERR_INVALID, "no sharded call yet");
+  hs_comm::Dev &d = *c->slots[c->last_slot].d[rank];
   if (d_labels32) *d_labels32 = d.all_l32.p;
   if (d_labels64) *d_labels64 = d.all_l64.p;
   if (d_dists) *d_dists = d.all_dist.p;

@@ -600,6 +600,16 @@ struct SlimGraph {
       for (int l = 1; l <= g.levels[v]; l++) add(n + in.upb[v] + l - 1, v, l);
     for (size_t t = 0; t < nt; t++)
       if (in.t_size[t] > 64) return false;
+    // what the device kernels index with: every list entry a node of at least the list's level (the reverse-edge kernels address
+    // task n + upb[u] + l - 1 for a level-l edge to u), 32-bit prefix sums.  A file that breaks this takes the CPU conversion.
+    if (nt >= 0xFFFFFFFFull || in.lists.size() >= 0xFFFFFFFFull || 2 * in.lists.size() >= 0xFFFFFFFFull) return false;
+    for (size_t t = 0; t < nt; t++) {
+      const uint32_t l = in.t_level[t];
+      for (uint32_t j = 0; j < in.t_size[t]; j++) {
+        const uint32_t u = in.lists[in.t_off[t] + j];
+        if (u >= n || (uint32_t)g.levels[u] < l) return false;
+      }
+    }
     std::vector<uint32_t> fin, fin_cnt;
     bool needs_host = false;
     hipError_t e = gpu_convert_lists(in, device, fin, fin_cnt, needs_host, kernel_ms);

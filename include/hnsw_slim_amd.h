@@ -166,7 +166,9 @@ void hs_host_free(void *p);
  * RCCL all-gather of the packed [S x k] results over xGMI leaves the whole [nq x k] result on every device and on the
  * host.  One process, one stream per device; parity = the single-device result, bit for bit.
  * hs_comm_init: devices = n_gpus HIP device ordinals (NULL: 0..n-1).  Listing one device more than once is the
- * one-GPU rehearsal mode (the exchange then runs as device copies instead of RCCL, which refuses duplicate devices). */
+ * one-GPU rehearsal mode (the exchange then runs as device copies instead of RCCL, which refuses duplicate devices).
+ * With more than one real device the first exchange happens here: a 64-byte all-gather per device, verified on every device
+ * (HS_ERR_DEVICE if RCCL, its datatype constants or a link are not what the search will rely on). */
 typedef struct hs_comm hs_comm;
 hs_status hs_comm_init(int n_gpus, const int *devices, hs_comm **out);
 void hs_comm_free(hs_comm *c);
@@ -175,6 +177,15 @@ int hs_comm_size(const hs_comm *c);
  * as for hs_search_batch; out_dists / out_counts nullable in HS_MODE_SLIM_IDS).  Synchronous. */
 hs_status hs_search_batch_sharded(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
                                   uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts);
+/* The same in two halves, for callers that keep several batches in flight per device (a split batch is a small launch on every
+ * device and lasts as long as its longest query; the chip fills up with several of them): hs_search_batch_sharded_async only
+ * ENQUEUES the step (H2D of the shards, search, all-gather, D2H of device 0's copy) on the streams of `slot`
+ * (0 <= slot < hs_comm_slots()); hs_comm_check(slot) waits for it and reports capacity errors.  queries and outputs must stay
+ * valid (page-locked if the copies are to overlap) until then; a slot holds one batch at a time. */
+int hs_comm_slots(const hs_comm *c);
+hs_status hs_search_batch_sharded_async(hs_comm *c, hs_index *const *ixs, const float *queries, size_t nq, size_t k, int mode,
+                                        uint32_t *out_labels32, uint64_t *out_labels64, float *out_dists, uint32_t *out_counts, int slot);
+hs_status hs_comm_check(hs_comm *c, hs_index *const *ixs, int slot);
 /* device `rank`'s copy of the gathered arrays of the last hs_search_batch_sharded call ([n_gpus * S x k]; valid until the next call) */
 hs_status hs_comm_results_dev(hs_comm *c, int rank, const uint32_t **d_labels32, const uint64_t **d_labels64,
                               const float **d_dists, const uint32_t **d_counts);

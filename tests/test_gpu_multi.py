@@ -61,6 +61,31 @@ def test_sharded_equals_single_device(hs, slim_file, n_dev):
         hs.Comm([0, 99])
 
 
+def test_sharded_async_slots_in_flight(hs, slim_file):
+    """hs_search_batch_sharded_async / hs_comm_check: three "devices" (loopback), six distinct batches in flight in six slots,
+    twice over (a slot is reused after its check); every batch equals the single-device call bit for bit; a slot that still
+    holds a batch refuses a second one."""
+    base_q = mixture(6 * 257, 32, 91)
+    reps = [hs.Index(slim_file, hs.HS_KIND_SLIM, 32) for _ in range(3)]
+    for r in reps:
+        r.set_ef(40)
+    comm = hs.Comm([0, 0, 0])
+    assert comm.slots() >= 6
+    qs = [hs.PinnedArray((257, 32), np.float32) for _ in range(6)]
+    outs = [hs.PinnedArray((257, 10), np.uint32) for _ in range(6)]
+    for rnd in range(2):
+        for b in range(6):
+            qs[b].a[:] = np.roll(base_q, rnd * 13, axis=0)[b * 257:(b + 1) * 257]
+            outs[b].a[:] = 0
+            comm.search_ids_async(reps, qs[b].a, 10, outs[b].a, slot=b)
+        with pytest.raises(hs.HsError):
+            comm.search_ids_async(reps, qs[0].a, 10, outs[0].a, slot=0)
+        for b in range(6):
+            comm.check(reps, b)
+            want = reps[0].search_ids(qs[b].a.copy(), 10)
+            assert np.array_equal(outs[b].a, want["labels"]), (rnd, b)
+
+
 def test_async_host_entry_overlapped_streams(hs, slim_file):
     """hs_search_batch_async: distinct batches in page-locked memory issued round-robin on three HIP streams; every batch's
     labels equal the synchronous call's."""

@@ -25,11 +25,12 @@ def per_launch(path, kernel_sub, counters):
 
 # A 10k-query pass of the fast kernel is two dispatches since round 2 (descent, then level-0 search in entry-distance order,
 # csrc/capi.cpp search_dev_group): "per launch" figures are per PASS, i.e. the per-dispatch average times two.
-DISPATCHES_PER_PASS = {"fast_kernel": 2, "lean_kernel": 2} if (len(sys.argv) > 1 and sys.argv[1] != "r01") else {}
+DISPATCHES_PER_PASS = {"fast_kernel": 2, "lean_kernel": 2, "flat_kernel": 2} if (len(sys.argv) > 1 and sys.argv[1] != "r01") else {}
 
 
 for s in ("1stream", "pipelined"):
     shutil.copy(os.path.join(SRC, f"bench_{s}.json"), os.path.join(DST, f"{tag}_bench_1gpu_{s}.json"))
+    os.makedirs(DST, exist_ok=True)
     ks = newest(f"kt_{s}/**/*kernel_stats.csv")
     rows = [l for i, l in enumerate(open(ks)) if i == 0 or "hs::" in l]
     open(os.path.join(DST, f"{tag}_kernel_stats_{s}.csv"), "w").writelines(rows)
@@ -46,7 +47,8 @@ hbm = fetch["FETCH_SIZE"] * 1024 * corr + write["WRITE_SIZE"] * 1024
 out = {
     "workload": f"SIFT-1M-like d=128 N=1000000 nq=10000 ef={ef} k=10, 1 stream",
     "ef": ef,
-    "kernel": "hs::" + KERNEL + (" (both dispatches of a pass: descent + level-0 search)" if DISPATCHES_PER_PASS else ""),
+    "kernel": "hs::" + KERNEL,
+    "kernel_note": "both dispatches of a pass: descent + level-0 search" if DISPATCHES_PER_PASS else "",
     "FETCH_SIZE_KiB_per_launch": round(fetch["FETCH_SIZE"], 1),
     "WRITE_SIZE_KiB_per_launch": round(write["WRITE_SIZE"], 1),
     "calibration": {
