@@ -102,6 +102,13 @@ struct SlimQIndex {
   }
 
   struct Query { float delta, vl, k1xsumq; std::vector<uint64_t> planes; std::vector<float> q2c; };
+  // Sensitivity probe (tools/slimq_sensitivity.py): move {delta, vl, k1xsumq, every q_to_centroids entry} by this many units in
+  // the last place after they have been computed -- how far may a different summation order (Eigen's, in the reference) move the ids?
+  int perturb_ulps[4] = {0, 0, 0, 0};
+  static float nudge(float v, int ulps) {
+    for (int i = 0; i < (ulps < 0 ? -ulps : ulps); i++) v = std::nextafter(v, ulps > 0 ? INFINITY : -INFINITY);
+    return v;
+  }
 
   // SplitSingleQuery ctor (rabitqlib/index/query.hpp:112-156) + centroid table (hnswalg_slimq.h:1822-1848)
   void prepare(const float *rq, Query &Q) const {
@@ -133,6 +140,12 @@ struct SlimQIndex {
       for (size_t i = 0; i < padded; i++) ip += rq[i] * ce[i];
       if (metric == METRIC_IP) { Q.q2c[c] = ip; Q.q2c[c + ncl] = std::sqrt(l2); }
       else Q.q2c[c] = std::sqrt(l2);
+    }
+    if (perturb_ulps[0] | perturb_ulps[1] | perturb_ulps[2] | perturb_ulps[3]) {
+      Q.delta = nudge(Q.delta, perturb_ulps[0]);
+      Q.vl = nudge(Q.vl, perturb_ulps[1]);
+      Q.k1xsumq = nudge(Q.k1xsumq, perturb_ulps[2]);
+      for (auto &v : Q.q2c) v = nudge(v, perturb_ulps[3]);
     }
   }
 

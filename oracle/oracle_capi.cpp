@@ -143,6 +143,7 @@ void hso_slimq_free(void *p) { delete (SlimQIndex *)p; }
 void hso_slimq_set(void *p, size_t ef, double t_const, const float *raw) {
   auto *ix = (SlimQIndex *)p; ix->ef = ef; ix->t_const = t_const; ix->raw = raw;
 }
+void hso_slimq_perturb(void *p, const int *ulps) { auto *ix = (SlimQIndex *)p; for (int i = 0; i < 4; i++) ix->perturb_ulps[i] = ulps[i]; }
 void hso_slimq_info(void *p, uint64_t *out) {
   auto *ix = (SlimQIndex *)p;
   out[0] = ix->count; out[1] = ix->dim; out[2] = ix->padded; out[3] = ix->ncl; out[4] = (uint64_t)ix->maxlevel;

@@ -10,6 +10,7 @@
 //                                                        rabitqlib/utils/warmup_space.hpp:8-102
 //   data   : one_bit_compact_code (1-bit code + f_add, f_rescale, f_error)
 //                                                        rabitqlib/quantization/rabitq_impl.hpp:75-187
+//   cent   : euclidean_sqr / dot_product (q_to_centroids) rabitqlib/utils/space.hpp:226-253
 //   buffer : rabitqlib::buffer::SearchBuffer            rabitqlib/utils/buffer.hpp:16-100
 // All arrays are raw little-endian binaries; shapes are passed on the command line (tests/golden/make_golden.py).
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include "rabitqlib/quantization/rabitq.hpp"
 #include "rabitqlib/utils/buffer.hpp"
 #include "rabitqlib/utils/rotator.hpp"
+#include "rabitqlib/utils/space.hpp"
 
 template <typename T>
 static std::vector<T> rd(const char *p, size_t n) {
@@ -101,6 +103,22 @@ int main(int argc, char **argv) {
     wr(argv[12], oq); wr(argv[13], ob); wr(argv[14], oe);
     return 0;
   }
+  if (c == "cent") {
+    // cent <padded> <rotq.f32> <nq> <cent.f32> <ncl> <out.f32: nq x ncl x 2 {euclidean_sqr, dot_product}>
+    // the two reductions HierarchicalNSWSlimQ::searchKnn takes q_to_centroids from (hnswalg_slimq.h:1823-1848):
+    // rabitqlib::euclidean_sqr / dot_product (rabitqlib/utils/space.hpp:226-253, Eigen .dot())
+    size_t padded = atoi(argv[2]), nq = atoi(argv[4]), ncl = atoi(argv[6]);
+    auto q = rd<float>(argv[3], nq * padded);
+    auto ce = rd<float>(argv[5], ncl * padded);
+    std::vector<float> out(nq * ncl * 2);
+    for (size_t i = 0; i < nq; i++)
+      for (size_t j = 0; j < ncl; j++) {
+        out[(i * ncl + j) * 2] = rabitqlib::euclidean_sqr(q.data() + i * padded, ce.data() + j * padded, padded);
+        out[(i * ncl + j) * 2 + 1] = rabitqlib::dot_product(q.data() + i * padded, ce.data() + j * padded, padded);
+      }
+    wr(argv[7], out);
+    return 0;
+  }
   if (c == "tconst") {  // tconst <padded> : one draw of faster_config(padded, 4).t_const (random, rabitq.hpp:27-34)
     auto cfg = rabitqlib::quant::faster_config(atoi(argv[2]), 4);
     printf("%.17g\n", cfg.t_const);
@@ -139,6 +157,6 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: ref_rabitq rotate|data|query|tconst|buffer ...\n");
+  fprintf(stderr, "usage: ref_rabitq rotate|data|query|cent|tconst|buffer ...\n");
   return 2;
 }

@@ -145,6 +145,25 @@ def rabitq_fixture(tmp):
     np.savez_compressed(os.path.join(GOLDEN, "rabitq_ref.npz"), **out)
 
 
+def rabitq_cent_fixture(tmp):
+    """q_to_centroids as the compiled rabitqlib computes it (hnswalg_slimq.h:1823-1848 -> rabitqlib::euclidean_sqr / dot_product,
+    Eigen reductions): the rotated queries of rabitq_ref.npz against 16 random rows per shape."""
+    RQ = os.path.join(ROOT, "oracle", "_ref", "ref_rabitq")
+    ref = np.load(os.path.join(GOLDEN, "rabitq_ref.npz"))
+    rng = np.random.default_rng(4242)
+    out = {}
+    for dim in (128, 96, 768):
+        rq = ref[f"d{dim}_rq"]
+        nq, padded = rq.shape
+        cen = (rng.standard_normal((16, padded)) * 0.7).astype(np.float32)
+        fq, fc, fo = (os.path.join(tmp, f"ct_{k}.bin") for k in ("q", "c", "o"))
+        rq.tofile(fq); cen.tofile(fc)
+        subprocess.check_call([RQ, "cent", str(padded), fq, str(nq), fc, "16", fo])
+        o = np.fromfile(fo, np.float32).reshape(nq, 16, 2)
+        out.update({f"d{dim}_cen": cen, f"d{dim}_l2sqr": o[:, :, 0].copy(), f"d{dim}_ip": o[:, :, 1].copy()})
+    np.savez_compressed(os.path.join(GOLDEN, "rabitq_cent_ref.npz"), **out)
+
+
 def bruteforce_fixture(tmp):
     """hnswlib::BruteforceSearch::searchKnn (bruteforce.h:106-135) of the compiled reference: continuous L2, tie-heavy integer
     L2 (ties across the k-th boundary) and inner product."""
@@ -203,6 +222,8 @@ def main():
                 bruteforce_fixture(tmp)
             if "buffer" in only:
                 searchbuffer_fixture(tmp)
+            if "cent" in only:
+                rabitq_cent_fixture(tmp)
         print("golden fixtures written:", sorted(only))
         return
     with tempfile.TemporaryDirectory() as tmp:
@@ -229,6 +250,7 @@ def main():
         for d, seed in ((20, 11), (21, 13), (10, 15)):
             index_fixture(tmp, f"l2_cont_d{d}", "l2", mixture(600, d, seed), mixture(40, d, seed + 1), 8, 60, [10, 32])
         rabitq_fixture(tmp)
+        rabitq_cent_fixture(tmp)
         # inner product off the SIMD16 path: SIMD4ExtAVX (d=20), SIMD16ExtResiduals (d=21), SIMD4ExtResiduals (d=10)
         ip_odd_dims_fixture(tmp)
         for d, seed in ((20, 21), (21, 23), (10, 25)):

@@ -128,6 +128,7 @@ class Oracle:
         L.hso_slimq_free.argtypes = [vp]
         L.hso_slimq_set.argtypes = [vp, sz, dbl, vp]
         L.hso_slimq_info.argtypes = [vp, vp]
+        L.hso_slimq_perturb.argtypes = [vp, vp]
         L.hso_slimq_search.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, ci]
         L.hso_slimq_prepare.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.hso_slimq_trace.restype = sz
@@ -224,6 +225,12 @@ class OracleSlimQ:
         self._raw = np.ascontiguousarray(raw, np.float32)
         assert self._raw.shape == (self.count, self.dim)
         self.o.L.hso_slimq_set(self.h, ef, float(t_const), self._raw.ctypes.data)
+
+    def perturb(self, ulps):
+        """Sensitivity probe: move {delta, vl, k1xsumq, q_to_centroids} by `ulps` units in the last place (4 ints; zeros = exact)."""
+        a = np.ascontiguousarray(ulps, np.int32)
+        assert a.shape == (4,)
+        self.o.L.hso_slimq_perturb(self.h, a.ctypes.data)
 
     def prepare(self, q):
         q = np.ascontiguousarray(q, np.float32)

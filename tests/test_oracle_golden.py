@@ -225,3 +225,32 @@ def test_slimq_oracle_pieces_match_rabitqlib(oracle, dim):
     assert np.array_equal(planes, RQ[p + "bins"])
     est = oracle.rq_est(metric, RQ[p + "codes"], RQ[p + "fac"], RQ[p + "q3"], RQ[p + "bins"], RQ[p + "g_add"])
     assert np.array_equal(est.view(np.uint32), RQ[p + "est"][:, :, 1].view(np.uint32))
+
+
+CQ = np.load(os.path.join(GOLDEN, "rabitq_cent_ref.npz"))
+
+
+def _ulps(a, b):
+    """distance in units in the last place between two float32 arrays of the same sign"""
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+@pytest.mark.parametrize("dim", (128, 96, 768))
+def test_q_to_centroids_against_compiled_rabitqlib(oracle, dim):
+    """q_to_centroids (hnswalg_slimq.h:1823-1848): sqrt(euclidean_sqr) and dot_product of the compiled rabitqlib (Eigen reductions,
+    whose order is alignment- and build-dependent) against the restatement's left-to-right fp32 sums.  Pinned to a few units in
+    the last place -- the size of the wobble tools/slimq_sensitivity.py perturbs by."""
+    rq, cen = RQ[f"d{dim}_rq"], CQ[f"d{dim}_cen"]
+    for metric in (0, 1):
+        _, _, q2c = oracle.rq_prepare(rq, metric, 41.25, cen)
+        want_l2 = np.sqrt(CQ[f"d{dim}_l2sqr"])
+        if metric == 0:
+            u = _ulps(np.ascontiguousarray(q2c, np.float32), want_l2.astype(np.float32))
+            assert u.max() <= 8, f"L2 norms differ by up to {u.max()} ulp"
+        else:
+            ncl = cen.shape[0]
+            ip, l2 = np.ascontiguousarray(q2c[:, :ncl], np.float32), np.ascontiguousarray(q2c[:, ncl:], np.float32)
+            assert _ulps(l2, want_l2.astype(np.float32)).max() <= 8
+            # a dot product near zero has no meaningful ulp distance: compare against the magnitude of the summands
+            scale = (np.abs(rq[:, None, :] * cen[None, :, :])).sum(-1)
+            assert np.all(np.abs(ip - CQ[f"d{dim}_ip"]) <= 4e-7 * scale)
