@@ -771,7 +771,11 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   static const char *kernel_env = getenv("HS_KERNEL");
   static const bool flatk_off = kernel_env && (!strcmp(kernel_env, "lean") || !strcmp(kernel_env, "fast"));
   const FlatPlan fp = plan_flat(ix, sh.ef, nq);
-  const bool flatk = !flatk_off && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);
+  // (long rows keep the fast kernel: its distance pass has the row's loads in flight 16-30 at a time with a compile-time dim,
+  //  the flat kernel walks dims beyond 128 eight 64-byte steps at a time; HS_KERNEL=flat forces it for the parity tests)
+  static const bool flatk_forced = kernel_env && !strcmp(kernel_env, "flat");
+  const bool flatk = !flatk_off && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k) &&
+                     (flatk_forced || ix->info.dim <= 256);
   ix->last_kernel = flatk ? "hs::flat_kernel" : lean ? "hs::lean_kernel" : fast ? "hs::fast_kernel" : "hs::strict_kernel";
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;

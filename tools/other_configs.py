@@ -21,17 +21,35 @@ else:
     def gen(m, seed):
         x = sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False, centre_lo=-60, centre_hi=60)
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
-t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
+# IDX_DIR: keep the data and index files there (a second, profiled run in the same gpurun call then skips the build);
+# PROFILE_EF: only the search at that ef, a few launches (what runs under rocprofv3)
+idir = os.environ.get("IDX_DIR") or tempfile.mkdtemp()
+os.makedirs(idir, exist_ok=True)
+hp, sp, bp, qp_ = (os.path.join(idir, f) for f in ("h.bin", "s.bin", "base.npy", "q.npy"))
 dev = torch.device("cuda", 0)
-with tempfile.TemporaryDirectory() as tmp:
-    hp, sp = os.path.join(tmp, "h.bin"), os.path.join(tmp, "s.bin")
+if os.path.exists(sp) and os.path.exists(bp):
+    base, q = np.load(bp, mmap_mode="r"), np.load(qp_)
+else:
+    t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
     thr = min(len(os.sched_getaffinity(0)), 64)
     t0 = time.time(); hs.build_hnsw(base, hp, M=16, ef_construction=200, threads=thr); tb = time.time() - t0
     t0 = time.time(); hs.convert_slim(hp, sp, d, threads=thr); tc = time.time() - t0
     print(f"build {tb:.0f}s convert {tc:.0f}s", flush=True)
-    ix = hs.Index(sp, hs.HS_KIND_SLIM, d)
-    ox = Oracle().load(sp, "slim", 0, d)
-bt = torch.from_numpy(base).to(dev); qt = torch.from_numpy(q).to(dev)
+    if os.environ.get("IDX_DIR"):
+        np.save(bp, base); np.save(qp_, q)
+ix = hs.Index(sp, hs.HS_KIND_SLIM, d)
+if os.environ.get("PROFILE_EF"):
+    ef = int(os.environ["PROFILE_EF"])
+    qt = torch.from_numpy(q).to(dev)
+    lab = torch.empty((nq, 10), dtype=torch.int32, device=dev); cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ix.set_ef(ef)
+    for _ in range(12):
+        ix.search_ids_dev(qt, 10, lab, None, cnt, None, s); ix.check(s)
+    print(f"profile run: {which} ef={ef}, 12 launches of {nq} queries, kernel {ix.last_kernel()}", flush=True)
+    sys.exit(0)
+ox = Oracle().load(sp, "slim", 0, d)
+bt = torch.from_numpy(np.ascontiguousarray(base)).to(dev); qt = torch.from_numpy(q).to(dev)
 gt = ground_truth(torch, bt, qt, 10, hs); del bt
 lab = torch.empty((nq, 10), dtype=torch.int32, device=dev); cnt = torch.empty((nq,), dtype=torch.int32, device=dev); st = torch.empty((nq, 4), dtype=torch.int32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
@@ -49,11 +67,12 @@ for ef in [int(e) for e in os.environ.get('EFS', '32,64,128,192,256,384,512').sp
     want = ox.search_ids(q[:200], 10, threads=32)
     same = bool(np.array_equal(np.sort(L[:200], axis=1), np.sort(want["labels"], axis=1))) and bool(np.array_equal(S[:200, :3], want["counters"][:, :3]))
     by = (S[:, 0] * 4 * d + S[:, 2] * 4 + S[:, 1] * 8)
-    print(f"ef={ef}: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} n_dist={S[:,0].mean():.0f} hops={S[:,1].mean():.0f} alg_GB/s={by.sum()/ms/1e6:.0f} "
+    print(f"ef={ef} [{ix.last_kernel()}]: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} n_dist={S[:,0].mean():.0f} hops={S[:,1].mean():.0f} alg_GB/s={by.sum()/ms/1e6:.0f} "
           f"frac={by.sum()/ms/1e6/8000:.3f} passes(tie/overflow)={(S[:,3]==1).sum()}/{(S[:,3]==2).sum()} oracle_match_first200={same}", flush=True)
     if op is None and recall_at_k(L, gt) >= 0.95:
         op = (ef, recall_at_k(L, gt), nq / ms * 1e3, by.sum() / ms / 1e6)
 if op:
+    open(os.path.join(idir, "operating_ef"), "w").write(str(op[0]))
     print(f"OPERATING POINT {which} n={n} d={d} nq={nq}: ef={op[0]} recall@10={op[1]:.4f} single-launch qps={op[2]:.0f} alg GB/s={op[3]:.0f} frac={op[3]/8000:.3f}", flush=True)
 else:
     print(f"OPERATING POINT {which}: recall@10 >= 0.95 not reached inside the sweep", flush=True)
