@@ -26,7 +26,8 @@ EXPORTS = [
     "hs_rabitq_estimate", "hs_convert_slimq", "hs_rabitq_default_tconst", "hs_slimq_set_dataset", "hs_slimq_set_tconst", "hs_slimq_get_tconst",
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
     "hs_search_batch_async", "hs_host_alloc", "hs_host_free", "hs_comm_init", "hs_comm_free", "hs_comm_size", "hs_search_batch_sharded",
-    "hs_comm_results_dev", "hs_convert_slim_gpu", "hs_index_patch", "hs_index_from_host_arrays",
+    "hs_comm_results_dev", "hs_convert_slim_gpu", "hs_index_patch", "hs_index_from_host_arrays", "hs_build_rabitq_hnsw",
+    "hs_convert_slimq_graph",
 ]
 
 
@@ -80,6 +81,7 @@ def lib():
     L.hs_search_batch_dev.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_search_check.argtypes = [vp, vp]
     L.hs_debug_heap_ops.argtypes = [vp, sz, ci, u32, vp, vp, vp]
+    L.hs_debug_flat_plan.argtypes = [sz, sz, sz, vp]
     L.hs_search_batch_async.argtypes = [vp, vp, sz, sz, ci, vp, vp, vp, vp, vp, vp]
     L.hs_host_alloc.restype = vp
     L.hs_host_alloc.argtypes = [sz]
@@ -99,6 +101,8 @@ def lib():
     L.hs_labels.argtypes = [vp, vp]
     L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
+    L.hs_convert_slimq_graph.argtypes = L.hs_convert_slim.argtypes
+    L.hs_build_rabitq_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim_gpu.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ci, ctypes.c_char_p,
                                       ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
     L.hs_convert_slimq.argtypes = [ctypes.c_char_p, ci, sz, vp, sz, vp, ctypes.c_uint64, ci, ctypes.c_char_p]
@@ -145,6 +149,21 @@ def convert_slim(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=
                                  top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
 
 
+def build_rabitq_hnsw(base, out_path, metric=HS_METRIC_L2, M=32, ef_construction=128, seed=100, threads=1):
+    """rabitqlib::hnsw::HierarchicalNSW::construct's edges (the graph HNSW-SlimQ converts from; defaults =
+    hnsw_slimq_strategy.h:106-108), saved in hnswlib's layout.  CPU harness."""
+    base = np.ascontiguousarray(base, np.float32)
+    _check(lib().hs_build_rabitq_hnsw(base.ctypes.data, base.shape[0], base.shape[1], metric, M, ef_construction, seed, threads,
+                                      out_path.encode()))
+
+
+def convert_slimq_graph(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=0, top_degree_percent0=0.02,
+                        top_degree_percent=0.02, top_degree_M0=32, low_degree_m0=8, top_degree_M=16, low_degree_m=4, threads=1):
+    """HierarchicalNSWSlimQ::convertFromHNSW's graph passes (its own PruneByHeuristic) -> Slim-layout file for convert_slimq."""
+    _check(lib().hs_convert_slimq_graph(hnsw_path.encode(), metric, dim, threshold_level, top_degree_percent0, top_degree_percent,
+                                        top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, threads, out_path.encode()))
+
+
 def convert_slim_gpu(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_level=0, top_degree_percent0=0.02,
                      top_degree_percent=0.02, top_degree_M0=32, low_degree_m0=8, top_degree_M=16, low_degree_m=4, device=0, threads=8):
     """convertFromHNSW with the per-list work on the GPU; returns (used_gpu, kernel_ms).  Same bytes as convert_slim."""
@@ -153,6 +172,12 @@ def convert_slim_gpu(hnsw_path, out_path, dim, metric=HS_METRIC_L2, threshold_le
                                      top_degree_M0, low_degree_m0, top_degree_M, low_degree_m, device, threads, out_path.encode(),
                                      ctypes.byref(used), ctypes.byref(ms)))
     return bool(used.value), ms.value
+
+
+def debug_flat_plan(n, ef, nq):
+    out = np.zeros(5, np.uint32)
+    _check(lib().hs_debug_flat_plan(n, ef, nq, out.ctypes.data))
+    return dict(nb=int(out[0]), mul=int(out[1]), sh=int(out[2]), bits=int(out[3]), ok=bool(out[4]))
 
 
 def debug_heap_ops(ops, wave_pop=True, lds_slots=1024):

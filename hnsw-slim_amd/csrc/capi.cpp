@@ -905,6 +905,16 @@ hs_status hs_search_check(hs_index *ix, void *stream) {
   return HS_OK;
 }
 
+// Parity/debug: the flat kernel's visited-set plan for an index of n nodes (dim 128) at (ef, nq): {buckets, multiplier, shift, id bits, ok}
+hs_status hs_debug_flat_plan(size_t n, size_t ef, size_t nq, uint32_t *out5) {
+  if (!out5) return fail(HS_ERR_INVALID, "null argument");
+  hs_index tmp;
+  tmp.info.n = n; tmp.info.dim = 128;
+  const FlatPlan f = plan_flat(&tmp, (uint32_t)ef, nq);
+  out5[0] = f.nb; out5[1] = f.mul; out5[2] = f.sh; out5[3] = f.vis_bits; out5[4] = f.ok ? 1u : 0u;
+  return HS_OK;
+}
+
 hs_status hs_debug_heap_ops(const uint32_t *ops, size_t n_ops, int wave_pop, uint32_t lds_slots, uint32_t *out_heap, uint32_t *out_pops,
                             uint32_t *out_n) {
   if (!ops || !out_heap || !out_pops || !out_n) return fail(HS_ERR_INVALID, "null argument");
@@ -1260,6 +1270,49 @@ hs_status hs_convert_slim(const char *hnsw_path, int metric, size_t dim, int thr
     p.top_M0 = top_degree_M0; p.low_m0 = low_degree_m0; p.top_M = top_degree_M; p.low_m = low_degree_m;
     SlimGraph s;
     s.convert(g, p, threads);
+    s.save(out_path);
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  return HS_OK;
+}
+
+// The base graph of HNSW-SlimQ: rabitqlib::hnsw::HierarchicalNSW::construct's edges (RqGraph in host_graph.hpp), stored in the
+// vanilla file layout so that the converters read it like any hnswlib index.
+hs_status hs_build_rabitq_hnsw(const float *base, size_t n, size_t dim, int metric, size_t M, size_t ef_construction, size_t seed,
+                               int threads, const char *out_path) {
+  if (!base || !out_path || n == 0 || dim == 0) return fail(HS_ERR_INVALID, "bad argument");
+  if (metric != HS_METRIC_L2 && metric != HS_METRIC_IP) return fail(HS_ERR_INVALID, "bad metric");
+  if (M < 2) return fail(HS_ERR_INVALID, "M must be >= 2");   // mult = 1 / ln M
+  try {
+    RqGraph g;
+    g.rq_build(base, n, dim, (Metric)metric, M, ef_construction, seed, threads);
+    g.save(out_path);
+  } catch (std::bad_alloc &) {
+    return fail(HS_ERR_NOMEM, "Not enough memory");
+  } catch (std::exception &e) {
+    return from_exception(e);
+  }
+  return HS_OK;
+}
+
+// HierarchicalNSWSlimQ::convertFromHNSW's graph passes (hnswalg_slimq.h:1546-1762): Slim's passes with SlimQ's own
+// PruneByHeuristic (:1334-1362) and rabitqlib's raw distance.  Output: a Slim-layout file for hs_convert_slimq.
+hs_status hs_convert_slimq_graph(const char *hnsw_path, int metric, size_t dim, int threshold_level, float top_degree_percent0,
+                                 float top_degree_percent, size_t top_degree_M0, size_t low_degree_m0, size_t top_degree_M,
+                                 size_t low_degree_m, int threads, const char *out_path) {
+  if (!hnsw_path || !out_path) return fail(HS_ERR_INVALID, "bad argument");
+  try {
+    VanillaGraph g;
+    g.load(hnsw_path, (Metric)metric, dim);
+    SlimParams p;
+    p.threshold_level = threshold_level;
+    p.top_pct0 = top_degree_percent0; p.top_pct = top_degree_percent;
+    p.top_M0 = top_degree_M0; p.low_m0 = low_degree_m0; p.top_M = top_degree_M; p.low_m = low_degree_m;
+    SlimGraph s;
+    s.convert(g, p, threads, true);
     s.save(out_path);
   } catch (std::bad_alloc &) {
     return fail(HS_ERR_NOMEM, "Not enough memory");

@@ -88,6 +88,48 @@ inline double branching_mult(const std::string &bf, size_t) {  // hnswalg.h:143-
   }
 }
 
+// raw_dist_func_ = euclidean_sqr / dot_product_dis (rabitqlib/utils/space.hpp:226-240): `(v0 - v1).dot(v0 - v1)` and
+// `1 - v0.dot(v1)` through the vendored Eigen's inner product (Eigen/src/Core/InnerProduct.h:113-159) with 16-float packets
+// (the AVX-512 build the parity flags pin): four packet accumulators, the first four packets multiplied, every later one
+// fused-multiply-added (pmadd = _mm512_fmadd_ps), folded 2+=3, 1+=2, 0+=1, then predux = halves 8, 4, (0+2, 1+3), (0+1)
+// (arch/AVX512/PacketMath.h:1456-1461, AVX :1954, SSE :1852-1853); the < 16 tail is a scalar fused chain.  Unlike the Eigen
+// reductions on the SEARCH path this one does not depend on pointer alignment: the operands are expressions.
+inline float rabitq_raw_dist(Metric metric, const float *a, const float *b, size_t d) {
+  const bool l2 = metric == METRIC_L2;
+  auto X = [&](size_t k) { return l2 ? a[k] - b[k] : a[k]; };
+  auto Y = [&](size_t k) { return l2 ? a[k] - b[k] : b[k]; };
+  float res;
+  if (d < 16) {
+    if (d == 0) return l2 ? 0.f : 1.f;
+    res = X(0) * Y(0);
+    for (size_t k = 1; k < d; k++) res = __builtin_fmaf(X(k), Y(k), res);
+  } else {
+    const size_t packet_end = d / 16 * 16, quad_end = d / 64 * 64, np = d / 16, nrem = (packet_end - quad_end) / 16;
+    float acc[4][16];
+    for (size_t p = 0; p < std::min<size_t>(np, 4); p++)
+      for (size_t j = 0; j < 16; j++) acc[p][j] = X(p * 16 + j) * Y(p * 16 + j);
+    if (np >= 4) {
+      for (size_t k = 64; k < quad_end; k += 64)
+        for (size_t p = 0; p < 4; p++)
+          for (size_t j = 0; j < 16; j++) acc[p][j] = __builtin_fmaf(X(k + p * 16 + j), Y(k + p * 16 + j), acc[p][j]);
+      for (size_t p = 0; p < nrem; p++)
+        for (size_t j = 0; j < 16; j++) acc[p][j] = __builtin_fmaf(X(quad_end + p * 16 + j), Y(quad_end + p * 16 + j), acc[p][j]);
+      for (size_t j = 0; j < 16; j++) acc[2][j] = acc[2][j] + acc[3][j];
+    }
+    if (np >= 3)
+      for (size_t j = 0; j < 16; j++) acc[1][j] = acc[1][j] + acc[2][j];
+    if (np >= 2)
+      for (size_t j = 0; j < 16; j++) acc[0][j] = acc[0][j] + acc[1][j];
+    float t8[8], t4[4];
+    for (size_t j = 0; j < 8; j++) t8[j] = acc[0][j] + acc[0][j + 8];
+    for (size_t j = 0; j < 4; j++) t4[j] = t8[j] + t8[j + 4];
+    const float u0 = t4[0] + t4[2], u1 = t4[1] + t4[3];
+    res = u0 + u1;
+    for (size_t k = packet_end; k < d; k++) res = __builtin_fmaf(X(k), Y(k), res);
+  }
+  return l2 ? res : 1 - res;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct VanillaGraph {
   size_t max_elements = 0, count = 0, dim = 0;
@@ -414,6 +456,206 @@ struct VanillaGraph {
 };
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// The base graph HNSW-SlimQ is converted from: rabitqlib::hnsw::HierarchicalNSW::construct
+// (/root/reference/third_party/rabitqlib/index/hnsw/hnsw.hpp:667-704, add_point :706-825, search_base_layer :827-905,
+// mutually_connect_new_element :907-1014, get_neighbors_by_heuristic2 :1016-1054), as include/strategy/hnsw_slimq_strategy.h:101-133
+// drives it (M = 32, ef_construction = 128, seed 100).  It "builds edges with non-quantized vectors" (:696): every distance is
+// get_data_dist on the RAW rows (:381-387), so this is hnswlib's insertion algorithm with three differences that change the graph:
+// the heaps order (distance, id) PAIRS lexicographically (maxheap = std::priority_queue<pair>, minheap with std::greater, :33-36)
+// instead of by distance alone, maxM = M and maxM0 = 2 M with mult = 1 / ln M (:445-493), and a neighbour that already lists the
+// new node is not connected twice (:973-980).  Storage and file layout are VanillaGraph's (hnswalg.h:748-779), so the Slim / SlimQ
+// converters read it like any vanilla index.
+struct RqGraph : VanillaGraph {
+  typedef std::pair<float, uint32_t> P;
+  typedef std::priority_queue<P> MaxH;
+  typedef std::priority_queue<P, std::vector<P>, std::greater<P>> MinH;
+  float ddist(uint32_t a, uint32_t b) const { return rabitq_raw_dist(metric, vec(a), vec(b), dim); }
+
+  MaxH rq_search_layer(uint32_t ep, uint32_t cur_c, int layer, Visited &vl) {   // :827-905
+    vl.begin(max_elements);
+    MaxH top;
+    MinH cand;
+    float lower = ddist(ep, cur_c);
+    top.emplace(lower, ep);
+    cand.emplace(lower, ep);
+    vl.mass[ep] = vl.cur;
+    while (!cand.empty()) {
+      const P c = cand.top();
+      if (c.first > lower && top.size() == efC) break;
+      cand.pop();
+      const uint32_t node = c.second;
+      std::unique_lock<std::mutex> lk(locks[node]);
+      const uint32_t *l = list_at(node, layer);
+      const size_t n = cnt_of(l);
+      for (size_t j = 0; j < n; j++) {
+        const uint32_t id = l[1 + j];
+        if (vl.mass[id] == vl.cur) continue;
+        vl.mass[id] = vl.cur;
+        const float d = ddist(id, cur_c);
+        if (top.size() < efC || lower > d) {
+          cand.emplace(d, id);
+          top.emplace(d, id);
+          if (top.size() > efC) top.pop();
+          if (!top.empty()) lower = top.top().first;
+        }
+      }
+    }
+    return top;
+  }
+  void rq_heuristic(MaxH &top, size_t Mlim) const {   // :1016-1054
+    if (top.size() < Mlim) return;
+    MinH closest;
+    std::vector<P> keep;
+    while (!top.empty()) { closest.emplace(top.top()); top.pop(); }
+    while (!closest.empty()) {
+      if (keep.size() >= Mlim) break;
+      const P cur = closest.top();
+      closest.pop();
+      bool good = true;
+      for (const P &sp : keep)
+        if (ddist(sp.second, cur.second) < cur.first) { good = false; break; }
+      if (good) keep.push_back(cur);
+    }
+    for (const P &pp : keep) top.emplace(pp);
+  }
+  uint32_t rq_connect(uint32_t cur_c, MaxH &top, int level) {   // :907-1014
+    const size_t max_m = level > 0 ? maxM : maxM0;
+    rq_heuristic(top, M);
+    if (top.size() > M) throw std::runtime_error("Should be not be more than M_ candidates returned by the heuristic");
+    std::vector<uint32_t> sel;
+    sel.reserve(M);
+    while (!top.empty()) { sel.push_back(top.top().second); top.pop(); }
+    const uint32_t next_ep = sel.back();
+    {
+      uint32_t *l = list_at(cur_c, level);
+      if (*l) throw std::runtime_error("The newly inserted element should have blank link list");
+      set_cnt(l, sel.size());
+      for (size_t i = 0; i < sel.size(); i++) {
+        if (l[1 + i]) throw std::runtime_error("Possible memory corruption");
+        if (level > levels[sel[i]]) throw std::runtime_error("Trying to make a link on a non-existent level");
+        l[1 + i] = sel[i];
+      }
+    }
+    for (uint32_t nb : sel) {
+      std::unique_lock<std::mutex> lk(locks[nb]);
+      uint32_t *lo = list_at(nb, level);
+      const size_t sz = cnt_of(lo);
+      if (sz > max_m) throw std::runtime_error("Bad value of sz_link_list_other");
+      if (nb == cur_c) throw std::runtime_error("Trying to connect an element to itself");
+      if (level > levels[nb]) throw std::runtime_error("Trying to make a link on a non-existent level");
+      uint32_t *data = lo + 1;
+      bool present = false;
+      for (size_t j = 0; j < sz; j++)
+        if (data[j] == cur_c) { present = true; break; }
+      if (present) continue;
+      if (sz < max_m) {
+        data[sz] = cur_c;
+        set_cnt(lo, sz + 1);
+      } else {
+        MaxH cands;
+        cands.emplace(ddist(nb, cur_c), cur_c);
+        for (size_t j = 0; j < sz; j++) cands.emplace(ddist(data[j], nb), data[j]);
+        rq_heuristic(cands, max_m);
+        int idx = 0;
+        while (!cands.empty()) { data[idx++] = cands.top().second; cands.pop(); }
+        set_cnt(lo, idx);
+      }
+    }
+    return next_ep;
+  }
+  void rq_add_point(const float *x, uint32_t cur_c, int curlevel, Visited &vl) {   // :706-825 (label == internal id)
+    std::unique_lock<std::mutex> lock_el(locks[cur_c]);
+    levels[cur_c] = curlevel;
+    std::unique_lock<std::mutex> templock(global);
+    const int maxlevelcopy = maxlevel;
+    if (curlevel <= maxlevelcopy) templock.unlock();
+    uint32_t curr = enterpoint;
+    memset(el(cur_c), 0, size_per_el);
+    const uint64_t label = cur_c;
+    memcpy(el(cur_c) + label_offset, &label, 8);
+    memcpy(el(cur_c) + offsetData, x, 4 * dim);
+    if (curlevel) links[cur_c].assign(size_links_up * curlevel + 1, 0);
+    if ((int32_t)curr != -1) {
+      if (curlevel < maxlevelcopy) {
+        float curdist = ddist(curr, cur_c);
+        for (int level = maxlevelcopy; level > curlevel; level--) {
+          bool changed = true;
+          while (changed) {
+            changed = false;
+            std::unique_lock<std::mutex> lk(locks[curr]);
+            const uint32_t *l = list_at(curr, level);
+            const int n = cnt_of(l);
+            for (int i = 0; i < n; i++) {
+              const uint32_t c = l[1 + i];
+              if (c > max_elements) throw std::runtime_error("cand error");
+              const float d = ddist(c, cur_c);
+              if (d < curdist) { curdist = d; curr = c; changed = true; }
+            }
+          }
+        }
+      }
+      for (int level = std::min(curlevel, maxlevelcopy); level >= 0; level--) {
+        MaxH top = rq_search_layer(curr, cur_c, level, vl);
+        curr = rq_connect(cur_c, top, level);
+      }
+    } else {
+      enterpoint = 0;
+      maxlevel = curlevel;
+    }
+    if (curlevel > maxlevelcopy) {
+      enterpoint = cur_c;
+      maxlevel = curlevel;
+    }
+  }
+  // rows 0..n-1, labels == row index; levels drawn up front in row order from std::default_random_engine(seed) (:222, 324-328, 477),
+  // so threads == 1 reproduces the reference's serial construct(); threads > 1 is as timing-dependent as the reference's own
+  // parallel_for (:698-703) but keeps ids == labels (the SlimQ rerank indexes raw rows by internal id, hnswalg_slimq.h:748).
+  void rq_build(const float *base, size_t n, size_t d, Metric m, size_t M_, size_t efC_, size_t seed, int threads) {
+    init(n, d, m, M_, efC_, "e");
+    mult = 1 / log(1.0 * (double)M);   // :493
+    std::default_random_engine gen;
+    gen.seed(seed);
+    std::vector<int> lv(n);
+    for (size_t i = 0; i < n; i++) {
+      std::uniform_real_distribution<double> distribution(0.0, 1.0);
+      lv[i] = (int)(-log(distribution(gen)) * mult);
+    }
+    if (threads < 1) threads = 1;
+    // the new element's row must be in place before anyone measures against it: rows are copied by rq_add_point itself, and
+    // get_data_dist(x, cur_c) reads row cur_c -> copy every row first (the reference reads rawDataPtr_, which is complete)
+    for (size_t i = 0; i < n; i++) memcpy(el((uint32_t)i) + offsetData, base + i * d, 4 * d);
+    Visited v0;
+    const size_t serial_head = threads > 1 ? std::min<size_t>(n, 1) : n;
+    auto add = [&](size_t i, Visited &vl) {
+      // (rq_add_point clears the element: keep the row)
+      rq_add_point(base + i * d, (uint32_t)i, lv[i], vl);
+    };
+    for (size_t i = 0; i < serial_head; i++) { count = i + 1; add(i, v0); }
+    if (serial_head < n) {
+      std::atomic<size_t> next(serial_head);
+      std::atomic<bool> failed(false);
+      std::string err;
+      std::mutex err_mu;
+      count = n;
+      std::vector<std::thread> pool;
+      for (int t = 0; t < threads; t++)
+        pool.emplace_back([&]() {
+          Visited vl;
+          while (true) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n || failed) break;
+            try { add(i, vl); }
+            catch (std::exception &e) { std::lock_guard<std::mutex> g(err_mu); err = e.what(); failed = true; }
+          }
+        });
+      for (auto &th : pool) th.join();
+      if (failed) throw std::runtime_error(err);
+    }
+    count = n;
+  }
+};
+
 struct SlimParams {
   int threshold_level = 0;
   float top_pct0 = 0.02f, top_pct = 0.02f;                 // alpha_0, alpha
@@ -438,6 +680,22 @@ struct SlimGraph {
   bool deleted(uint32_t i) const { return (((const unsigned char *)el(i))[6] & 1) != 0; }  // hnswalg_slim.h:1776-1781
 
   // PruneByHeuristic (hnswalg_slim.h:836-865): input sorted ascending by distance.
+  // HierarchicalNSWSlimQ's own PruneByHeuristic (hnswalg_slimq.h:1334-1362), mirrored as written: the occlusion test measures the
+  // candidate against the node whose INTERNAL ID is the loop index i over the sorted candidates (`hnsw->get_data_dist(i, ...)`,
+  // :1349), not against the neighbours kept so far, and only once something has been kept.
+  static void prune_slimq(const VanillaGraph &g, const std::vector<pairfi> &sorted, std::vector<uint32_t> &out, size_t Mlim) {
+    out.clear();
+    for (size_t i = 0; i < sorted.size(); i++) {
+      if (out.size() >= Mlim) break;
+      const pairfi &cur = sorted[i];
+      bool good = true;
+      if (!out.empty()) {
+        float d = rabitq_raw_dist(g.metric, g.vec((uint32_t)i), g.vec(cur.second), g.dim);
+        if (d < cur.first) good = false;
+      }
+      if (good) out.push_back(cur.second);
+    }
+  }
   static void prune(const VanillaGraph &g, const std::vector<pairfi> &sorted, std::vector<uint32_t> &out, size_t Mlim) {
     out.clear();
     for (const pairfi &cur : sorted) {
@@ -510,8 +768,17 @@ struct SlimGraph {
     memcpy(blobs[i].data() + 2 * (size_t)L, nbrs_out.data(), 4 * (size_t)total);
   }
 
-  // convertFromHNSW (hnswalg_slim.h:867-1108).
-  void convert(const VanillaGraph &g, const SlimParams &p, int threads) {
+  // convertFromHNSW (hnswalg_slim.h:867-1108); slimq_prune: HierarchicalNSWSlimQ::convertFromHNSW's graph part
+  // (hnswalg_slimq.h:1471-1762: the same passes with its own PruneByHeuristic).
+  void convert(const VanillaGraph &g, const SlimParams &p, int threads, bool slimq_prune = false) {
+    auto prune = [&](const VanillaGraph &gg, const std::vector<pairfi> &sorted, std::vector<uint32_t> &out, size_t Mlim) {
+      if (slimq_prune) SlimGraph::prune_slimq(gg, sorted, out, Mlim);
+      else SlimGraph::prune(gg, sorted, out, Mlim);
+    };
+    // distances: hnsw->fstdistfunc_ (hnswalg_slim.h:977-979) / hnsw->get_data_dist (hnswalg_slimq.h:1623, 1706)
+    auto D = [&](uint32_t a, uint32_t b) {
+      return slimq_prune ? rabitq_raw_dist(g.metric, g.vec(a), g.vec(b), g.dim) : g.dist(g.vec(a), g.vec(b));
+    };
     take_header(g, p);
     const size_t n = count;
     const std::vector<size_t> thr = hub_thresholds(g, p);
@@ -533,7 +800,7 @@ struct SlimGraph {
         size_t size = VanillaGraph::cnt_of(ll);
         size_t M0 = l == 0 ? (size > thr[l] ? p.top_M0 : p.low_m0) : (size > thr[l] ? p.top_M : p.low_m);
         heap.resize(size);
-        for (size_t j = 0; j < size; j++) heap[j] = {g.dist(g.vec(v), g.vec(ll[1 + j])), ll[1 + j]};
+        for (size_t j = 0; j < size; j++) heap[j] = {D(v, ll[1 + j]), ll[1 + j]};
         std::sort(heap.begin(), heap.end(), CmpFirst());
         prune(g, heap, nn[v][l], M0);
       }
@@ -558,7 +825,7 @@ struct SlimGraph {
         size_t limit = l == 0 ? maxM0 : maxM;
         if (nbrs.size() > limit) {  // re-prune (:1038-1062)
           heap.resize(nbrs.size());
-          for (size_t j = 0; j < nbrs.size(); j++) heap[j] = {g.dist(g.vec(i), g.vec(nbrs[j])), nbrs[j]};
+          for (size_t j = 0; j < nbrs.size(); j++) heap[j] = {D((uint32_t)i, nbrs[j]), nbrs[j]};
           std::sort(heap.begin(), heap.end(), CmpFirst());
           prune(g, heap, nbrs, limit);
         }

@@ -144,6 +144,10 @@ hs_status hs_search_check(hs_index *ix, void *stream);
  * hnswalg_slim.h:177-183, 331-332, 353-354, 408-411) through the flat kernel's heap code on the device.  ops: 3 words each
  * {0 = push | 1 = pop, distance bits, id}; wave_pop selects the whole-wave pop; lds_slots: heap slots kept in LDS (the rest
  * in global memory).  out_heap / out_pops: 2 words per entry (n_ops entries of room each); out_n: {final size, pops}. */
+/* Parity/debug entry (host only, no device needed): the flat kernel's visited-set plan for an index of n nodes at (ef, queries per
+ * call): out5 = {buckets nb, multiplier m, shift s, id-space bits B, ok}; bucket = h mod nb and remainder = h div nb =
+ * umulhi(h, m) >> s must be exact for every h < 2^B and the remainders must fit 15 bits (tests/test_host_cpu.py). */
+hs_status hs_debug_flat_plan(size_t n, size_t ef, size_t nq, uint32_t *out5);
 hs_status hs_debug_heap_ops(const uint32_t *ops, size_t n_ops, int wave_pop, uint32_t lds_slots, uint32_t *out_heap, uint32_t *out_pops,
                             uint32_t *out_n);
 
@@ -260,6 +264,22 @@ hs_status hs_convert_slim_gpu(const char *hnsw_path, int metric, size_t dim, int
                               float top_degree_percent0, float top_degree_percent, size_t top_degree_M0,
                               size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int device, int threads,
                               const char *out_path, int *used_gpu, double *kernel_ms);
+
+/* The graph HNSW-SlimQ is converted FROM: rabitqlib::hnsw::HierarchicalNSW(num_points, dim, total_bits, M, ef_construction,
+ * random_seed, metric) + construct() (third_party/rabitqlib/index/hnsw/hnsw.hpp:427-500, 667-1054), as
+ * include/strategy/hnsw_slimq_strategy.h:106-121 drives it with M = 32, ef_construction = 128, seed 100.  Edges come from the RAW
+ * rows (hnsw.hpp:381-387) in Eigen's inner-product order; heaps order (distance, id) pairs; mult = 1 / ln M.  Only the edges are
+ * built here (the RaBitQ records are hs_convert_slimq's job); the file is hnswlib's saveIndex layout (hnswalg.h:748-779), labels ==
+ * row index == internal id.  threads == 1 reproduces the reference's serial construct() edge for edge. */
+hs_status hs_build_rabitq_hnsw(const float *base, size_t n, size_t dim, int metric, size_t M, size_t ef_construction,
+                               size_t seed, int threads, const char *out_path);
+/* HierarchicalNSWSlimQ::convertFromHNSW's graph passes (hnswalg_slimq.h:1546-1762): hs_convert_slim's passes with SlimQ's own
+ * PruneByHeuristic as written (:1334-1362 -- the occlusion test reads the row whose id is the LOOP INDEX, :1349) and rabitqlib's
+ * raw distance (:1623, :1706).  Writes a Slim-layout file; feed it to hs_convert_slimq for the quantised index. */
+hs_status hs_convert_slimq_graph(const char *hnsw_path, int metric, size_t dim, int threshold_level,
+                                 float top_degree_percent0, float top_degree_percent, size_t top_degree_M0,
+                                 size_t low_degree_m0, size_t top_degree_M, size_t low_degree_m, int threads,
+                                 const char *out_path);
 
 /* HierarchicalNSWSlimQ::convertFromHNSW's OUTPUT format + saveIndex (hnswalg_slimq.h:1471-1790, 1161-1216): keeps
  * the graph of an existing HierarchicalNSWSlim file and replaces the fp32 rows by RaBitQ records (cluster id,

@@ -12,6 +12,8 @@
 //                                                        rabitqlib/quantization/rabitq_impl.hpp:75-187
 //   cent   : euclidean_sqr / dot_product (q_to_centroids) rabitqlib/utils/space.hpp:226-253
 //   buffer : rabitqlib::buffer::SearchBuffer            rabitqlib/utils/buffer.hpp:16-100
+//   hnsw   : rabitqlib::hnsw::HierarchicalNSW ctor + construct (the graph HNSW-SlimQ is converted from), serial
+//                                                        rabitqlib/index/hnsw/hnsw.hpp:427-500, 667-1054
 // All arrays are raw little-endian binaries; shapes are passed on the command line (tests/golden/make_golden.py).
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "rabitqlib/index/estimator.hpp"
+#include "rabitqlib/index/hnsw/hnsw.hpp"
 #include "rabitqlib/index/query.hpp"
 #include "rabitqlib/quantization/rabitq.hpp"
 #include "rabitqlib/utils/buffer.hpp"
@@ -157,6 +160,35 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: ref_rabitq rotate|data|query|cent|tconst|buffer ...\n");
+  if (c == "hnsw") {
+    // hnsw <n> <dim> <metric 0=L2 1=IP> <M> <efC> <seed> <base.f32> <out.u32>
+    // One centroid (row 0) and cluster id 0 for every point: the edges come from the raw rows alone (hnsw.hpp:381-387, 696);
+    // num_threads = 1 -> parallel_for's serial loop (ivf/initializer.hpp:23-26).  out: maxlevel, enterpoint, then per node in id
+    // order: label, level, and per level 0..level: count, ids.
+    size_t n = atol(argv[2]), dim = atol(argv[3]);
+    int metric = atoi(argv[4]);
+    size_t M = atol(argv[5]), efc = atol(argv[6]), seed = atol(argv[7]);
+    auto base = rd<float>(argv[8], n * dim);
+    rabitqlib::hnsw::HierarchicalNSW h(n, dim, 4, M, efc, seed, metric ? rabitqlib::METRIC_IP : rabitqlib::METRIC_L2);
+    std::vector<rabitqlib::PID> cid(n, 0);
+    h.construct(1, base.data(), n, base.data(), cid.data(), 1, true);
+    std::vector<uint32_t> out;
+    out.push_back((uint32_t)h.maxlevel_);
+    out.push_back((uint32_t)h.enterpoint_node_);
+    for (size_t i = 0; i < n; i++) {
+      out.push_back((uint32_t)h.get_external_label(i));
+      const int lv = h.element_levels_[i];
+      out.push_back((uint32_t)lv);
+      for (int l = 0; l <= lv; l++) {
+        const rabitqlib::PID *ll = l == 0 ? h.get_linklist0(i) : h.get_linklist(i, l);
+        const size_t cnt = h.get_list_count(ll);
+        out.push_back((uint32_t)cnt);
+        for (size_t j = 0; j < cnt; j++) out.push_back(ll[1 + j]);
+      }
+    }
+    wr(argv[9], out);
+    return 0;
+  }
+  fprintf(stderr, "usage: ref_rabitq rotate|data|query|cent|tconst|buffer|hnsw ...\n");
   return 2;
 }

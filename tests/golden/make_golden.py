@@ -164,6 +164,36 @@ def rabitq_cent_fixture(tmp):
     np.savez_compressed(os.path.join(GOLDEN, "rabitq_cent_ref.npz"), **out)
 
 
+RQ_HNSW_CASES = [   # (name, n, dim, metric, M, efC, integer-valued)
+    ("l2_d64", 1500, 64, 0, 8, 40, False), ("l2_d100", 1200, 100, 0, 6, 30, False), ("ip_d128", 1500, 128, 1, 8, 40, False),
+    ("l2_int_d64", 1500, 64, 0, 8, 40, True), ("ip_d72", 800, 72, 1, 4, 20, False), ("l2_d112_m32", 900, 112, 0, 32, 128, False),
+]
+
+
+def rq_hnsw_base(n, d, metric, integer):
+    if integer:
+        return np.ascontiguousarray(mixture(n, d, 3, lo=2, hi=8, sigma=2.0, integer=True), np.float32)
+    b = mixture(n, d, 5, lo=-1, hi=1, sigma=0.5)
+    if metric:
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+    return np.ascontiguousarray(b, np.float32)
+
+
+def rq_hnsw_fixture(tmp):
+    """The graph HNSW-SlimQ converts from, as the compiled rabitqlib builds it serially (hnsw.hpp:667-1054; seed 100):
+    [maxlevel, enterpoint, then per node: label, level, per level count + ids].  The rows are regenerated from the seeds."""
+    RQ = os.path.join(ROOT, "oracle", "_ref", "ref_rabitq")
+    out = {}
+    for name, n, d, metric, M, efc, integer in RQ_HNSW_CASES:
+        b = rq_hnsw_base(n, d, metric, integer)
+        fb, fo = os.path.join(tmp, "rqb.bin"), os.path.join(tmp, "rqo.bin")
+        b.tofile(fb)
+        subprocess.check_call([RQ, "hnsw", str(n), str(d), str(metric), str(M), str(efc), "100", fb, fo], stdout=subprocess.DEVNULL)
+        out[name] = np.fromfile(fo, np.uint32)
+        out[name + "_rowsum"] = np.float64(b.astype(np.float64).sum())   # guards the regenerated rows
+    np.savez_compressed(os.path.join(GOLDEN, "rabitq_hnsw_ref.npz"), **out)
+
+
 def bruteforce_fixture(tmp):
     """hnswlib::BruteforceSearch::searchKnn (bruteforce.h:106-135) of the compiled reference: continuous L2, tie-heavy integer
     L2 (ties across the k-th boundary) and inner product."""
@@ -224,6 +254,8 @@ def main():
                 searchbuffer_fixture(tmp)
             if "cent" in only:
                 rabitq_cent_fixture(tmp)
+            if "rqhnsw" in only:
+                rq_hnsw_fixture(tmp)
         print("golden fixtures written:", sorted(only))
         return
     with tempfile.TemporaryDirectory() as tmp:
@@ -251,6 +283,7 @@ def main():
             index_fixture(tmp, f"l2_cont_d{d}", "l2", mixture(600, d, seed), mixture(40, d, seed + 1), 8, 60, [10, 32])
         rabitq_fixture(tmp)
         rabitq_cent_fixture(tmp)
+        rq_hnsw_fixture(tmp)
         # inner product off the SIMD16 path: SIMD4ExtAVX (d=20), SIMD16ExtResiduals (d=21), SIMD4ExtResiduals (d=10)
         ip_odd_dims_fixture(tmp)
         for d, seed in ((20, 21), (21, 23), (10, 25)):

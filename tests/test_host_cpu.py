@@ -158,3 +158,30 @@ def test_hot_kernels_keep_their_wave_budget():
         assert name in kern, f"{name} missing from resource_usage.txt"
         vgpr, scratch, occ = kern[name]
         assert occ >= waves and scratch == 0, f"{name}: {vgpr} VGPRs, {scratch} B scratch, {occ} waves/SIMD (budget {waves})"
+
+
+def test_flat_kernel_visited_set_plan_divides_exactly():
+    """The flat kernel's visited set keeps id i in bucket h mod nb with remainder h div nb, h = (i * odd) mod 2^B a bijection of the
+    id space (csrc/flat_search.hip); the division is umulhi(h, m) >> s.  For every plan the host makes -- any index size, ef, launch
+    size -- that must be exact over the whole id space and the remainder must fit the 15 bits a bucket slot has."""
+    hs = load_product()
+    rng = np.random.default_rng(11)
+    shapes = [(1000, 10, 1), (100_000, 64, 100), (1_000_000, 70, 10_000), (1_000_000, 256, 1250), (17_500_000, 100, 200),
+              (100_000_000, 256, 10_000), (2_000_000_000, 128, 10_000)]
+    shapes += [(int(rng.integers(2, 1 << 31)), int(rng.integers(1, 257)), int(rng.integers(1, 40_000))) for _ in range(40)]
+    for n, ef, nq in shapes:
+        p = hs.debug_flat_plan(n, ef, nq)
+        assert (1 << p["bits"]) >= n and p["bits"] <= 31
+        if not p["ok"]:
+            continue
+        nb, m, s, B = p["nb"], p["mul"], p["sh"], p["bits"]
+        assert ((1 << B) - 1) // nb <= 32767, (n, ef, nq, p)
+        if B <= 22:
+            h = np.arange(1 << B, dtype=np.uint64)
+        else:
+            edge = np.array([0, 1, nb - 1, nb, nb + 1, (1 << B) - 1, (1 << B) - 2, ((1 << B) // nb) * nb, ((1 << B) // nb) * nb - 1], np.uint64)
+            mult = (rng.integers(1, (1 << B) // nb + 1, size=200_000).astype(np.uint64) * np.uint64(nb))
+            mult = mult[mult < (1 << B)]
+            h = np.concatenate([edge, rng.integers(0, 1 << B, size=1_000_000).astype(np.uint64), mult, mult - np.uint64(1)])
+        q = ((h * np.uint64(m)) >> np.uint64(32)) >> np.uint64(s)
+        assert np.array_equal(q, h // np.uint64(nb)), (n, ef, nq, p)

@@ -23,36 +23,57 @@ else:
         G = [float(v) for v in os.environ.get("GEN", "256,24,40,1.5,40").split(",")]
         x = sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False, centre_lo=-G[4], centre_hi=G[4])
         return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
-t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
+# IDX_DIR: keep data + index files (a profiled second run skips generation and build); PROFILE_EF: only the search at that ef
+idir = os.environ.get("IDX_DIR") or tempfile.mkdtemp()
+os.makedirs(idir, exist_ok=True)
+hp, sp, qp, bp, qf = (os.path.join(idir, f) for f in ("h.bin", "s.bin", "q.bin", "base.npy", "queries.npy"))
 dev = torch.device("cuda", 0)
-bt = torch.from_numpy(base).to(dev); qt = torch.from_numpy(q).to(dev)
-# exact ground truth on the GPU (plumbing): L2 or inner product
-out = []
-bn = (bt * bt).sum(1)
-for s0 in range(0, nq, 512):
-    sc = qt[s0:s0 + 512] @ bt.T
-    dist = bn[None, :] - 2.0 * sc if metric == 0 else -sc
-    out.append(torch.topk(dist, 10, dim=1, largest=False).indices)
-gt = torch.cat(out).cpu().numpy(); del out, bn
-# 16 centroids by a few Lloyd rounds on a sample (the reference takes them from a k-means script: hnsw_slimq_strategy.h:101-106)
-rng = np.random.default_rng(0)
-samp = bt[torch.from_numpy(rng.choice(n, min(n, 200_000), replace=False)).to(dev)]
-cen = samp[:16].clone()
-for _ in range(8):
-    a = torch.cdist(samp, cen).argmin(1)
-    for c in range(16):
-        m = a == c
-        if m.any(): cen[c] = samp[m].mean(0)
-cen = cen.cpu().numpy(); del samp, bt
-with tempfile.TemporaryDirectory() as tmp:
-    hp, sp, qp = (os.path.join(tmp, f) for f in ("h.bin", "s.bin", "q.bin"))
+profile_ef = int(os.environ.get("PROFILE_EF", "0"))
+if os.path.exists(qp) and os.path.exists(bp):
+    base, q = np.load(bp, mmap_mode="r"), np.load(qf)
+    qt = torch.from_numpy(q).to(dev)
+    gt = None
+else:
+    t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
+    bt = torch.from_numpy(base).to(dev); qt = torch.from_numpy(q).to(dev)
+    # exact ground truth on the GPU (plumbing): L2 or inner product
+    out = []
+    bn = (bt * bt).sum(1)
+    for s0 in range(0, nq, 512):
+        sc = qt[s0:s0 + 512] @ bt.T
+        dist = bn[None, :] - 2.0 * sc if metric == 0 else -sc
+        out.append(torch.topk(dist, 10, dim=1, largest=False).indices)
+    gt = torch.cat(out).cpu().numpy(); del out, bn
+    # 16 centroids by a few Lloyd rounds on a sample (the reference takes them from a k-means script: hnsw_slimq_strategy.h:101-106)
+    rng = np.random.default_rng(0)
+    samp = bt[torch.from_numpy(rng.choice(n, min(n, 200_000), replace=False)).to(dev)]
+    cen = samp[:16].clone()
+    for _ in range(8):
+        a = torch.cdist(samp, cen).argmin(1)
+        for c in range(16):
+            m = a == c
+            if m.any(): cen[c] = samp[m].mean(0)
+    cen = cen.cpu().numpy(); del samp, bt
     thr = min(len(os.sched_getaffinity(0)), 64)
     t0 = time.time(); hs.build_hnsw(base, hp, metric=metric, M=16, ef_construction=200, threads=thr); tb = time.time() - t0
     t0 = time.time(); hs.convert_slim(hp, sp, d, metric=metric, threads=thr); tc = time.time() - t0
     t0 = time.time(); hs.convert_slimq(sp, metric, d, cen, qp, threads=thr); tq = time.time() - t0
     print(f"build {tb:.0f}s convert {tc:.0f}s quantise {tq:.0f}s  slim {os.path.getsize(sp)/1e6:.0f} MB slimq {os.path.getsize(qp)/1e6:.0f} MB", flush=True)
-    ix = hs.Index(qp, hs.HS_KIND_SLIMQ, d, metric=metric)
-    ox = Oracle().load_slimq(qp)
+    if os.environ.get("IDX_DIR"):
+        np.save(bp, base); np.save(qf, q)
+ix = hs.Index(qp, hs.HS_KIND_SLIMQ, d, metric=metric)
+if profile_ef:
+    ix.slimq_set_dataset(np.ascontiguousarray(base))
+    ix.set_ef(profile_ef)
+    lab = torch.empty((nq, 10), dtype=torch.int64, device=dev); dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(12):
+        ix.slimq_search_dev(qt, 10, lab, dd, cnt, None, s); ix.check(s)
+    print(f"profile run: {which} ef={profile_ef}, 12 launches of {nq} queries, kernel {ix.last_kernel()}", flush=True)
+    sys.exit(0)
+ox = Oracle().load_slimq(qp)
+base = np.ascontiguousarray(base)
 ix.slimq_set_dataset(base)
 ox.set(64, ix.slimq_tconst(), base)
 gp, op = ix.slimq_prepare_debug(q, ox.padded, ox.ncl), ox.prepare(q)
