@@ -153,7 +153,11 @@ static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 can
 static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)
 static constexpr uint32_t kHopCap = 4096;      // 4 KiB per query: accepted neighbours per expansion (flat start of the fast kernel)
 static constexpr uint32_t kParkWords = 2048;   // 8 KiB per query: where the flat kernel parks the head of its visited set during a heap replay
-static constexpr uint32_t kSpillStride = kSpillSlots + 2 * kCand2Cap + 2 * kLogCap + kHopCap / 4 + kParkWords;  // words per query
+// words of scratch per query; beyond ef = 256 (the flat kernel's S = 6, 8 shapes: up to ~3 k accepted neighbours and > 1 k hops per
+// query at ef = 512) the insertion and hop logs are twice / four times as long
+static uint32_t log_cap_for(uint32_t ef) { return ef <= 256 ? kLogCap : 2 * kLogCap; }
+static uint32_t hop_cap_for(uint32_t ef) { return ef <= 256 ? kHopCap : 4 * kHopCap; }
+static uint32_t spill_stride_for(uint32_t ef) { return kSpillSlots + 2 * kCand2Cap + 2 * log_cap_for(ef) + hop_cap_for(ef) / 4 + kParkWords; }
 
 static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   const size_t ef = std::max(ix->ef, k);
@@ -234,7 +238,8 @@ static FlatPlan plan_flat(const hs_index *ix, uint32_t ef, size_t nq) {
   nb = std::max<uint32_t>(nb, 8);
   if (!ix->user_hash_slots) {
     const size_t total = flatk_lds_bytes(dim, ef, nb);
-    static const size_t max_waves = getenv("HS_FLAT_WAVES_PER_CU") ? (size_t)atoi(getenv("HS_FLAT_WAVES_PER_CU")) : 20;   // diagnostic: builds with another residency
+    static const size_t env_waves = getenv("HS_FLAT_WAVES_PER_CU") ? (size_t)atoi(getenv("HS_FLAT_WAVES_PER_CU")) : 0;   // diagnostic: builds with another residency
+    const size_t max_waves = env_waves ? env_waves : flatk_waves_per_cu(dim, ef);
     size_t waves = std::min<size_t>(max_waves, kLdsPerCU / std::max<size_t>(total, 1));
     waves = std::min(waves, std::max<size_t>((nq + 255) / 256, 1));   // a launch smaller than the wave slots: fewer, larger shares
     if (waves >= 1) {
@@ -711,7 +716,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   HIP_TRY(hipSetDevice(ix->device));
   hs_index::StreamWs *w = ix->stream_ws(stream);
   HIP_TRY(w->status.ensure(nq));
-  HIP_TRY(w->spill.ensure(nq * (size_t)kSpillStride));
+  HIP_TRY(w->spill.ensure(nq * (size_t)spill_stride_for(sh.ef)));
   // (status needs no clearing: pass 0 takes every query and writes each one's final status)
   // counters[0..12): per-pass overflow / hazard counts.  They are STICKY: they accumulate over the launch groups of a call and
   // over every call issued on this stream until hs_search_check reads and clears them, so a capacity failure in any batch of
@@ -730,8 +735,8 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   a.out_labels32 = l32; a.out_labels64 = l64; a.out_dists = dd; a.out_counts = cnt; a.stats = stats;
   a.raw_top = raw; a.raw_size = rawsz; a.raw_stride = sh.ef;
   a.status = w->status.p;
-  a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = kSpillStride; a.cand2_cap = kCand2Cap; a.log_cap = kLogCap;
-  a.hop_cap = kHopCap;
+  a.spill = w->spill.p; a.spill_slots = kSpillSlots; a.spill_stride = spill_stride_for(sh.ef); a.cand2_cap = kCand2Cap;
+  a.log_cap = log_cap_for(sh.ef); a.hop_cap = hop_cap_for(sh.ef);
   static const bool flat_off = getenv("HS_FLAT") && atoi(getenv("HS_FLAT")) == 0;   // diagnostic: heap path from the first expansion
   a.flat = flat_off ? 0u : 1u;
   // A launch that cannot fill the GPU anyway (fewer queries than wavefront slots) lasts as long as its longest query, and
@@ -771,11 +776,7 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
   static const char *kernel_env = getenv("HS_KERNEL");
   static const bool flatk_off = kernel_env && (!strcmp(kernel_env, "lean") || !strcmp(kernel_env, "fast"));
   const FlatPlan fp = plan_flat(ix, sh.ef, nq);
-  // (long rows keep the fast kernel: its distance pass has the row's loads in flight 16-30 at a time with a compile-time dim,
-  //  the flat kernel walks dims beyond 128 eight 64-byte steps at a time; HS_KERNEL=flat forces it for the parity tests)
-  static const bool flatk_forced = kernel_env && !strcmp(kernel_env, "flat");
-  const bool flatk = !flatk_off && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k) &&
-                     (flatk_forced || ix->info.dim <= 256);
+  const bool flatk = !flatk_off && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);
   ix->last_kernel = flatk ? "hs::flat_kernel" : lean ? "hs::lean_kernel" : fast ? "hs::fast_kernel" : "hs::strict_kernel";
   a.queue = w->counters.p + 12;
   a.counters = w->counters.p; a.pass_id = 0;

@@ -90,6 +90,7 @@ hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stre
 // Flat kernel (flat_search.hip): lazy candidate heap -- replayed from the insertion log only when its layout decides a pop.
 bool flatk_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
 size_t flatk_lds_bytes(uint32_t dim, uint32_t ef, uint32_t nb);
+uint32_t flatk_waves_per_cu(uint32_t dim, uint32_t ef);
 hipError_t launch_flatk(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 hipError_t flat_heap_ops(const uint32_t *d_ops, uint32_t n_ops, uint2 *d_spill, uint2 *d_heap, uint2 *d_pops, uint32_t *d_n, int wave_pop,
                          uint32_t lds_slots, hipStream_t stream);

@@ -23,7 +23,7 @@
 //   * Distances: 8 lanes per row, 8 rows per pass (lean_search.hip's mapping); the left-to-right sum of the sixteen AVX-512 lane
 //     accumulators is seven (v_add_f32 with a DPP row_shr:1 operand, v_add_f32) pairs; the result stays in the group's last lane.
 //
-// Serves bare indexes (no delete marks / filter) with level-0 tiles, threshold_level 0, dim % 16 == 0, ef <= 256, k <= 64.
+// Serves bare indexes (no delete marks / filter) with level-0 tiles, threshold_level 0, dim % 16 == 0, ef <= 512, k <= 64.
 // Replaces (paths relative to /root/reference/third_party/hnswlib/): HierarchicalNSWSlim::searchKnn 2030-2131 / 1907-2028,
 // searchBaseLayerST<bare_bone> hnswalg_slim.h:321-457, HierarchicalNSW::searchKnn / searchBaseLayerST hnswalg.h:1378-1440 /
 // 326-479, space_l2.h:25-54, space_ip.h:146-199, visited_list_pool.h:10-31.
@@ -90,6 +90,20 @@ __device__ __forceinline__ int wave_min_i32_f(int v) {
   return min(min(r0, r1), min(r2, r3));
 }
 
+// loads in flight per lane for a compile-time dim of D16 sixteen-float steps
+__host__ __device__ constexpr int flat_row_buffer(int d16) {
+  return d16 <= 0 ? 1 : d16 <= 8 ? d16 : d16 % 30 == 0 ? 30 : d16 % 32 == 0 ? 32 : d16 % 24 == 0 ? 24 : 16;
+}
+// Wavefronts per SIMD a shape is compiled for: 5 (96 VGPRs, 8 KiB of LDS each) for the common shapes; result sets beyond 256
+// entries (S = 6, 8: twelve / sixteen more registers) and long rows (a 16..32-deep load buffer) get 128 .. 256 VGPRs.
+__host__ __device__ constexpr int flat_waves(int s, int d16) {
+#ifdef HS_FLAT_WAVES
+  return HS_FLAT_WAVES;
+#else
+  return d16 > 8 ? 2 : d16 < 0 ? 3 : s > 4 ? 4 : 5;
+#endif
+}
+
 // One pass of distances: the 8 lanes of group g = lane >> 3 work on row `rowid`; the group's lane OWN (7 for L2, 0 for IP)
 // returns the distance in the reference's summation order (space_l2.h:36-51, space_ip.h:183-197); other lanes: unspecified.
 template <int METRIC, int D16>
@@ -97,42 +111,51 @@ __device__ __forceinline__ float flat_dist8(const float *vec, uint32_t dim, cons
   const hs_f2 *row = reinterpret_cast<const hs_f2 *>(vec + (size_t)rowid * dim) + s;
   const lds_f2 *qq = reinterpret_cast<const lds_f2 *>(qv) + s;
   hs_f2 acc = {0.f, 0.f};
+  auto step = [&](const hs_f2 q2, const hs_f2 x) {
+    if (METRIC == METRIC_L2) {
+      const hs_f2 t = q2 - x;
+      const hs_f2 p = t * t;
+      acc = acc + p;
+    } else {
+      acc = __builtin_elementwise_fma(q2, x, acc);
+    }
+  };
   if (D16 > 0) {
-    constexpr int B = D16 > 0 ? D16 : 1;
+    // compile-time dim: the whole row in flight up to d = 128; longer rows in rounds of up to 32 eight-byte loads per lane
+    // (d = 960: two rounds of 30 -- 7.5 KB per wave and round; those instantiations run at 3 wavefronts per SIMD, flat_waves())
+    constexpr int B = flat_row_buffer(D16);
+    constexpr int R = (D16 > 0 ? D16 : 1) / B, T = (D16 > 0 ? D16 : 1) % B;
     hs_f2 buf[B];
 #pragma unroll
     for (int i = 0; i < B; i++) buf[i] = row[i * 8];
 #pragma unroll
-    for (int i = 0; i < B; i++) {
-      const hs_f2 q2 = qq[i * 8];
-      if (METRIC == METRIC_L2) {
-        const hs_f2 t = q2 - buf[i];
-        const hs_f2 p = t * t;
-        acc = acc + p;
-      } else {
-        acc = __builtin_elementwise_fma(q2, buf[i], acc);
-      }
+    for (int i = 0; i < B; i++) step(qq[i * 8], buf[i]);
+#pragma unroll 1
+    for (int r = 1; r < R; r++) {
+#pragma unroll
+      for (int i = 0; i < B; i++) buf[i] = row[(r * B + i) * 8];
+#pragma unroll
+      for (int i = 0; i < B; i++) step(qq[(r * B + i) * 8], buf[i]);
+    }
+    if (T > 0) {
+#pragma unroll
+      for (int i = 0; i < T; i++) buf[i] = row[(R * B + i) * 8];
+#pragma unroll
+      for (int i = 0; i < T; i++) step(qq[(R * B + i) * 8], buf[i]);
     }
   } else {
+    // runtime dim: rounds of 8 (D16 == 0) or 16 (D16 == -1: rows beyond 1 KB) loads in flight
+    constexpr uint32_t RB = D16 == 0 ? 8u : 16u;
     const uint32_t steps = dim >> 4;
-    for (uint32_t r0 = 0; r0 < steps; r0 += 8) {
-      const uint32_t nb = min(8u, steps - r0);
-      hs_f2 buf[8];
+    for (uint32_t r0 = 0; r0 < steps; r0 += RB) {
+      const uint32_t nb = min(RB, steps - r0);
+      hs_f2 buf[RB];
 #pragma unroll
-      for (uint32_t i = 0; i < 8; i++)
+      for (uint32_t i = 0; i < RB; i++)
         if (i < nb) buf[i] = row[(r0 + i) * 8];
 #pragma unroll
-      for (uint32_t i = 0; i < 8; i++)
-        if (i < nb) {
-          const hs_f2 q2 = qq[(r0 + i) * 8];
-          if (METRIC == METRIC_L2) {
-            const hs_f2 t = q2 - buf[i];
-            const hs_f2 p = t * t;
-            acc = acc + p;
-          } else {
-            acc = __builtin_elementwise_fma(q2, buf[i], acc);
-          }
-        }
+      for (uint32_t i = 0; i < RB; i++)
+        if (i < nb) step(qq[(r0 + i) * 8], buf[i]);
     }
   }
   if (METRIC == METRIC_L2) {
@@ -923,11 +946,8 @@ __device__ int search_one_flat(const DevIndex &ix, const SearchArgs &a, const ui
   return 0;
 }
 
-#ifndef HS_FLAT_WAVES
-#define HS_FLAT_WAVES 5
-#endif
 template <int METRIC, int S, int D16>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HS_FLAT_WAVES))) flat_kernel(DevIndex ix, SearchArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(flat_waves(S, D16)))) flat_kernel(DevIndex ix, SearchArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   lds_u8 *smem = (lds_u8 *)smem_raw;
   for (uint32_t it = blockIdx.x; it < a.nq; it += gridDim.x) {
@@ -954,12 +974,16 @@ static hipError_t flat_launch_d(const DevIndex &ix, const SearchArgs &a, hipStre
   const size_t lds = flat_layout(ix.dim, a.ef, a.fl_nb).total;
   if (a.ef <= 64) return flat_launch(flat_kernel<METRIC, 1, D16>, ix, a, lds, stream);
   if (a.ef <= 128) return flat_launch(flat_kernel<METRIC, 2, D16>, ix, a, lds, stream);
-  return flat_launch(flat_kernel<METRIC, 4, D16>, ix, a, lds, stream);
+  if (a.ef <= 256) return flat_launch(flat_kernel<METRIC, 4, D16>, ix, a, lds, stream);
+  if (a.ef <= 384) return flat_launch(flat_kernel<METRIC, 6, D16>, ix, a, lds, stream);
+  return flat_launch(flat_kernel<METRIC, 8, D16>, ix, a, lds, stream);
 }
 template <int METRIC>
 static hipError_t flat_launch_s(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
   if (ix.dim == 128) return flat_launch_d<METRIC, 8>(ix, a, stream);
   if (ix.dim == 96) return flat_launch_d<METRIC, 6>(ix, a, stream);
+  if (ix.dim == 960) return flat_launch_d<METRIC, 60>(ix, a, stream);
+  if (ix.dim > 256) return flat_launch_d<METRIC, -1>(ix, a, stream);
   return flat_launch_d<METRIC, 0>(ix, a, stream);
 }
 
@@ -1007,7 +1031,13 @@ hipError_t launch_flatk_ip(const DevIndex &ix, const SearchArgs &a, hipStream_t 
 #if !defined(HS_TU_METRIC) || HS_TU_METRIC == 0
 bool flatk_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
   return ix.tile0 != nullptr && (ix.maxlevel == 0 || ix.uptile != nullptr) && ix.threshold_level == 0 && !ix.has_deleted && ix.n > 0 &&
-         ix.n < kFDone && (ix.dim & 15u) == 0 && ef >= k && ef <= 256 && k <= 64;
+         ix.n < kFDone && (ix.dim & 15u) == 0 && ef >= k && ef <= 512 && k <= 64;
+}
+// wavefronts per CU the shape's kernel is resident with (the LDS share of a wave follows from it: capi.cpp plan_flat)
+uint32_t flatk_waves_per_cu(uint32_t dim, uint32_t ef) {
+  const int s = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 384 ? 6 : 8;
+  const int d16 = dim == 128 ? 8 : dim == 96 ? 6 : dim == 960 ? 60 : dim > 256 ? -1 : 0;
+  return 4u * (uint32_t)flat_waves(s, d16);
 }
 size_t flatk_lds_bytes(uint32_t dim, uint32_t ef, uint32_t nb) { return flat_layout(dim, ef, nb).total; }
 hipError_t launch_flatk_l2(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) { return flat_launch_s<METRIC_L2>(ix, a, stream); }

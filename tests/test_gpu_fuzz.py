@@ -42,7 +42,7 @@ def test_fuzz_slim(env, tmp_path, seed):
     ox = O.load(sp, "slim", L2, d)
     allowed = (rng.random(n) < 0.7).astype(np.uint8) if seed % 3 == 0 else None
     for _ in range(3):
-        ef, k = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+        ef, k = int(rng.integers(1, 520)), int(rng.integers(1, 40))
         cfg = f"seed={seed} n={n} d={d} M={M} int={integer} thr={thr} ef={ef} k={k}"
         if min(ef, k) > n:
             continue
@@ -82,7 +82,7 @@ def test_fuzz_vanilla(env, tmp_path, seed):
     ix = P.Index(hp, P.HS_KIND_HNSW, d, metric)
     ox = O.load(hp, "hnsw", metric, d)
     for _ in range(3):
-        ef, k = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+        ef, k = int(rng.integers(1, 520)), int(rng.integers(1, 40))
         cfg = f"seed={seed} n={n} d={d} M={M} metric={metric} ef={ef} k={k}"
         ix.set_ef(ef); ox.set_ef(ef)
         op = ox.search_pq(q, k, threads=4)

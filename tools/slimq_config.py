@@ -2,7 +2,9 @@
 """HNSW-SlimQ (RaBitQ) at size: parity against the oracle on a query sample + throughput / recall sweep.
 Usage: slimq_config.py sift|cohere [n]
   sift   : the bench's SIFT-1M-like data, d=128 L2  (same graph as the fp32 bench line, quantised)
-  cohere : COHERE-1M-like, d=768 inner product on unit vectors (BASELINE.json configs[4])"""
+  cohere : COHERE-1M-like, d=768 inner product on unit vectors (BASELINE.json configs[4])
+env GRAPH=rq : build the base graph the way the reference's SlimQ strategy does (rabitqlib HNSW M=32/efC=128 + SlimQ's prune)
+               instead of the fp32 bench line's hnswlib graph"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -55,8 +57,16 @@ else:
             if m.any(): cen[c] = samp[m].mean(0)
     cen = cen.cpu().numpy(); del samp, bt
     thr = min(len(os.sched_getaffinity(0)), 64)
-    t0 = time.time(); hs.build_hnsw(base, hp, metric=metric, M=16, ef_construction=200, threads=thr); tb = time.time() - t0
-    t0 = time.time(); hs.convert_slim(hp, sp, d, metric=metric, threads=thr); tc = time.time() - t0
+    if os.environ.get("GRAPH", "hnswlib") == "rq":
+        # the reference's own SlimQ pipeline (hnsw_slimq_strategy.h:106-128): rabitqlib's HNSW (M=32, efC=128, seed 100) + SlimQ's own
+        # PruneByHeuristic in convertFromHNSW (hnswalg_slimq.h:1334-1362)
+        t0 = time.time(); hs.build_rabitq_hnsw(base, hp, metric=metric, M=32, ef_construction=128, seed=100, threads=thr); tb = time.time() - t0
+        t0 = time.time(); hs.convert_slimq_graph(hp, sp, d, metric=metric, threads=thr); tc = time.time() - t0
+        print("graph: rabitqlib-style HNSW M=32 efC=128 + SlimQ prune", flush=True)
+    else:
+        t0 = time.time(); hs.build_hnsw(base, hp, metric=metric, M=16, ef_construction=200, threads=thr); tb = time.time() - t0
+        t0 = time.time(); hs.convert_slim(hp, sp, d, metric=metric, threads=thr); tc = time.time() - t0
+        print("graph: hnswlib HNSW M=16 efC=200 + Slim prune", flush=True)
     t0 = time.time(); hs.convert_slimq(sp, metric, d, cen, qp, threads=thr); tq = time.time() - t0
     print(f"build {tb:.0f}s convert {tc:.0f}s quantise {tq:.0f}s  slim {os.path.getsize(sp)/1e6:.0f} MB slimq {os.path.getsize(qp)/1e6:.0f} MB", flush=True)
     if os.environ.get("IDX_DIR"):
@@ -90,6 +100,8 @@ s = torch.cuda.current_stream().cuda_stream
 streams = [torch.cuda.Stream() for _ in range(4)]
 outs = [(torch.empty_like(lab), torch.empty_like(dd), torch.empty_like(cnt)) for _ in range(4)]
 rec_bytes = 16 + (d + 63) // 64 * 8
+tile = max(16, (int(ix.info()["max_degree0"]) + 15) // 16 * 16)   # ids per adjacency tile (capi.cpp tile_stride_for)
+print("adjacency tile", tile, "ids", flush=True)
 for ef in [int(e) for e in os.environ.get("EFS", "64,128,256,512,1024").split(",")]:
     ix.set_ef(ef); ox.set(ef, ix.slimq_tconst(), base)
     for _ in range(2):
@@ -134,6 +146,6 @@ for ef in [int(e) for e in os.environ.get("EFS", "64,128,256,512,1024").split(",
             print("   extra candidate", cand, "popped before:", cand in pops_before, "times inserted before:", sum(1 for v in to[:j] if int(v) == (cand | 0x40000000)))
             import pickle; pickle.dump(dict(tg=tg, to=to, q=q[i]), open(os.path.join(ROOT, "gpurun_out", "slimq_diverge.pkl"), "wb"))
         print("   gpu dists", dd.cpu().numpy()[i].tolist(), "\n   ora dists", want["dists"][i].tolist(), flush=True)
-    by = S[:, 1] * rec_bytes + S[:, 0] * (4 * d + 4 * 32)   # estimates x record + expansions x (raw row + adjacency tile)
+    by = S[:, 1] * rec_bytes + S[:, 0] * (4 * d + 4 * tile)   # estimates x record + expansions x (raw row + adjacency tile)
     print(f"ef={ef}: recall@10={recall_at_k(L, gt):.4f} qps={nq/ms*1e3:.0f} ms={ms:.3f} qps_4streams={nq/ms4*1e3:.0f} hops={S[:,0].mean():.0f} est={S[:,1].mean():.0f} ins={S[:,2].mean():.0f} "
           f"revisit={S[:,3].mean():.0f} alg_GB/s={by.sum()/ms/1e6:.0f} oracle_match_first200={same} oracle_32thr_qps={200/tcpu:.0f}", flush=True)
