@@ -92,7 +92,11 @@ __device__ __forceinline__ int wave_min_i32_f(int v) {
 
 // loads in flight per lane for a compile-time dim of D16 sixteen-float steps
 __host__ __device__ constexpr int flat_row_buffer(int d16) {
+#ifdef HS_FLAT_LONG_B   // A/B knob (make flatvar): loads in flight per round for rows beyond 512 B
+  return d16 <= 0 ? 1 : d16 <= 8 ? d16 : (d16 < HS_FLAT_LONG_B ? d16 : HS_FLAT_LONG_B);
+#else
   return d16 <= 0 ? 1 : d16 <= 8 ? d16 : d16 % 30 == 0 ? 30 : d16 % 32 == 0 ? 32 : d16 % 24 == 0 ? 24 : 16;
+#endif
 }
 // Wavefronts per SIMD a shape is compiled for: 5 (96 VGPRs, 8 KiB of LDS each) for the common shapes; result sets beyond 256
 // entries (S = 6, 8: twelve / sixteen more registers) and long rows (a 16..32-deep load buffer) get 128 .. 256 VGPRs.
@@ -100,7 +104,11 @@ __host__ __device__ constexpr int flat_waves(int s, int d16) {
 #ifdef HS_FLAT_WAVES
   return HS_FLAT_WAVES;
 #else
+#ifdef HS_FLAT_LONG_WAVES
+  return d16 > 8 ? HS_FLAT_LONG_WAVES : d16 < 0 ? 3 : s > 4 ? 4 : 5;
+#else
   return d16 > 8 ? 2 : d16 < 0 ? 3 : s > 4 ? 4 : 5;
+#endif
 #endif
 }
 
@@ -121,15 +129,21 @@ __device__ __forceinline__ float flat_dist8(const float *vec, uint32_t dim, cons
     }
   };
   if (D16 > 0) {
-    // compile-time dim: the whole row in flight up to d = 128; longer rows in rounds of up to 32 eight-byte loads per lane
-    // (d = 960: two rounds of 30 -- 7.5 KB per wave and round; those instantiations run at 3 wavefronts per SIMD, flat_waves())
+    // compile-time dim: the whole row in flight up to d = 128; longer rows in rounds of up to 32 eight-byte loads per lane.  d = 960
+    // (two rounds of 30) is compiled for 2 wavefronts per SIMD (flat_waves()): with 256 VGPRs the compiler issues both rounds'
+    // loads before the first use, and -- what decides -- keeps the hop's state out of scratch memory: the 3-wave build (168
+    // VGPRs, 270 B of scratch per lane, reloads between the loads) took 5.55 ms for a 1000-query launch at ef = 384, this one
+    // 3.38 ms, a 1-wave build with spills to AGPRs 3.20 ms (profiles/r03_longrow_ab.log, tools/r03_longrow_ab.sh).
     constexpr int B = flat_row_buffer(D16);
     constexpr int R = (D16 > 0 ? D16 : 1) / B, T = (D16 > 0 ? D16 : 1) % B;
     hs_f2 buf[B];
 #pragma unroll
     for (int i = 0; i < B; i++) buf[i] = row[i * 8];
 #pragma unroll
-    for (int i = 0; i < B; i++) step(qq[i * 8], buf[i]);
+    for (int i = 0; i < B; i++) {
+      if (B > 8 && i % 8 == 0) __builtin_amdgcn_sched_barrier(0);   // (keeps the query's LDS reads from being hoisted sixty deep)
+      step(qq[i * 8], buf[i]);
+    }
 #pragma unroll 1
     for (int r = 1; r < R; r++) {
 #pragma unroll

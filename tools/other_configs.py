@@ -4,6 +4,8 @@ DEEP-like d=96 (configs[3]).  Usage: other_configs.py gist|deep [n]     env GEN=
 generator (calibration runs), EFS the sweep.  Prints the sweep and, for the smallest ef with recall@10 >= 0.95, the operating point."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("DIAG_EF"):   # phase stamps of the flat kernel (make -C hnsw-slim_amd flatdiag) at that ef instead of the sweep
+    os.environ["HS_LIB"] = os.path.join(ROOT, "hnsw-slim_amd", "libhnsw_slim_amd_flatdiag.so")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
 import torch
@@ -47,6 +49,26 @@ if os.environ.get("PROFILE_EF"):
     for _ in range(12):
         ix.search_ids_dev(qt, 10, lab, None, cnt, None, s); ix.check(s)
     print(f"profile run: {which} ef={ef}, 12 launches of {nq} queries, kernel {ix.last_kernel()}", flush=True)
+    sys.exit(0)
+if os.environ.get("DIAG_EF"):
+    qt = torch.from_numpy(q).to(dev)
+    lab = torch.empty((nq, 10), dtype=torch.int32, device=dev); cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((5 * nq, 4), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for ef in [int(e) for e in os.environ["DIAG_EF"].split(",")]:
+        ix.set_ef(ef)
+        for _ in range(3):
+            ix.search_ids_dev(qt, 10, lab, None, cnt, stats, s); ix.check(s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ix.search_ids_dev(qt, 10, lab, None, cnt, stats, s); e1.record(); torch.cuda.synchronize()
+        h = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        s4, dg = h[:nq], h[nq:].reshape(nq, 16)
+        wall, hops = dg[:, 0] / 100.0, s4[:, 1]
+        ph = dg[:, 8:14].astype(np.float64)
+        names = ["select", "tile wait", "visited+compaction", "rows+distances", "accept(+pre-select)", "hop end"]
+        print(f"DIAG {which} ef={ef} [{ix.last_kernel()}]: launch {e0.elapsed_time(e1):.3f} ms; query wall us mean {wall.mean():.0f} max {wall.max():.0f}; hops mean {hops.mean():.0f} max {hops.max()}; "
+              f"us/hop {wall.sum() / hops.sum():.2f}; n_dist/hop {s4[:, 0].sum() / hops.sum():.2f}; pre-selected {dg[:, 6].sum() / hops.sum() * 100:.0f}%")
+        print("   shader cycles per hop: " + ", ".join(f"{nm} {ph[:, i].sum() / hops.sum():.0f}" for i, nm in enumerate(names)) + f"; sum {ph.sum() / hops.sum():.0f}", flush=True)
     sys.exit(0)
 ox = Oracle().load(sp, "slim", 0, d)
 bt = torch.from_numpy(np.ascontiguousarray(base)).to(dev); qt = torch.from_numpy(q).to(dev)

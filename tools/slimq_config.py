@@ -34,7 +34,7 @@ profile_ef = int(os.environ.get("PROFILE_EF", "0"))
 if os.path.exists(qp) and os.path.exists(bp):
     base, q = np.load(bp, mmap_mode="r"), np.load(qf)
     qt = torch.from_numpy(q).to(dev)
-    gt = None
+    gt = np.load(os.path.join(idir, "gt.npy")) if os.path.exists(os.path.join(idir, "gt.npy")) else None
 else:
     t0 = time.time(); base = gen(n, 123); q = gen(nq, 456); print(f"{which}: generated n={n} d={d} in {time.time()-t0:.0f}s", flush=True)
     bt = torch.from_numpy(base).to(dev); qt = torch.from_numpy(q).to(dev)
@@ -70,7 +70,7 @@ else:
     t0 = time.time(); hs.convert_slimq(sp, metric, d, cen, qp, threads=thr); tq = time.time() - t0
     print(f"build {tb:.0f}s convert {tc:.0f}s quantise {tq:.0f}s  slim {os.path.getsize(sp)/1e6:.0f} MB slimq {os.path.getsize(qp)/1e6:.0f} MB", flush=True)
     if os.environ.get("IDX_DIR"):
-        np.save(bp, base); np.save(qf, q)
+        np.save(bp, base); np.save(qf, q); np.save(os.path.join(idir, "gt.npy"), gt)
 ix = hs.Index(qp, hs.HS_KIND_SLIMQ, d, metric=metric)
 if profile_ef:
     ix.slimq_set_dataset(np.ascontiguousarray(base))
