@@ -391,13 +391,9 @@ hipError_t launch_slimq_prep(const DevSlimQ &sq, uint32_t dim, int metric, const
   return hipGetLastError();
 }
 
-#ifndef HS_SLIMQ_PREFETCH
-#define HS_SLIMQ_PREFETCH 1
-#endif
 template <int METRIC, int S, int NBLK, bool DBG = false>
 __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
-  constexpr bool PREFETCH = HS_SLIMQ_PREFETCH != 0 && !DBG;
   const SlimQLds L = slimq_layout(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
   uint64_t *planes_lds = reinterpret_cast<uint64_t *>(smem + L.off_planes);
@@ -576,9 +572,6 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     wave_sync();
   };
 
-  // touch loads (see scan): the value of one touch is folded into pf_sink when the NEXT one is issued -- by then it has long
-  // arrived, so the fold costs no wait -- and pf_sink is looked at once after the loop, which keeps the loads from being removed
-  uint32_t pf_sink = 0, pf_tile = 0, pf_row = 0;
   while (ps.cur != kNoRank) {
     const uint32_t node = pool_pop<S>(pval, ps, lane);
     const bool seen = set_has(tab, mask, node);
@@ -600,36 +593,6 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
       // is_full() can only turn true as the scan proceeds (the last key never grows once the buffer is full), so
       // the pre-test with the state at the start of the tile rejects nothing the sequential scan would accept
       unsigned long long pendm = hs_ballot(act && !(d > ps.last) && !set_has(tab, mask, c));
-      if (PREFETCH && sq.ftile != nullptr) {
-        // The node of the NEXT expansion, before this tile's insertions have run: the nearest candidate about to be inserted (it
-        // always is: the bound cannot fall below the smallest key being inserted; among equals the last one inserted ends up in
-        // front, insert() places a key before its equals) or the buffer's current first unchecked entry, whichever is nearer.
-        // Its fused tile is touched now (one dword per 128-byte line, value unused), so that the dependent read at the top of
-        // the next iteration meets the lines in L2 instead of HBM while the insertions below run.  A hint only: nothing depends
-        // on the guess being right (the popped node may also turn out to be an expanded one).
-        const bool mine = (pendm >> lane) & 1ull;
-        const float dmin = wave_min_f32(mine ? d : INFINITY);
-        const unsigned long long at_min = hs_ballot(mine && d == dmin);
-        float kcur = INFINITY;
-        uint32_t icur = kNoneQ;
-        if (ps.cur != kNoRank) {
-          const uint32_t sc = ps.cur >> 6, lc = ps.cur & 63;
-#pragma unroll
-          for (int s = 0; s < S; s++)
-            if ((uint32_t)s == sc) {
-              kcur = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pkey[s]), lc));
-              icur = __builtin_amdgcn_readlane(pval[s], lc);
-            }
-        }
-        uint32_t nxt = icur;
-        if (at_min != 0ull && !(dmin > kcur)) nxt = __builtin_amdgcn_readlane(c, 63 - __clzll((long long)at_min));
-        if (nxt != kNoneQ) {
-          const uint32_t *nrow = sq.ftile + (size_t)(nxt & ~kChecked) * ((size_t)ix.tile_stride * sq.rec_words);
-          const uint32_t lines = (ix.tile_stride * sq.rec_words + 31u) >> 5;   // 128-byte lines of the tile
-          for (uint32_t l0 = 0; l0 < lines; l0 += 64)
-            if (l0 + lane < lines) { pf_sink ^= pf_tile; pf_tile = nrow[(size_t)(l0 + lane) * 32u]; }
-        }
-      }
       while (pendm) {
         const int l = __ffsll((long long)pendm) - 1;
         pendm &= pendm - 1;
@@ -672,10 +635,6 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     if (!any) continue;   // neighbors == nullptr / size == 0: not reranked either (:708-715)
     n_hops++;
     if (lane == 0) pend[n_pend] = node;
-    if (PREFETCH) {   // the raw row of the deferred exact re-rank (flush, up to 16 expansions later): touch its lines now
-      const uint32_t lines = (ix.dim * 4u + 127u) >> 7;
-      if ((uint32_t)lane < lines) { pf_sink ^= pf_row; pf_row = reinterpret_cast<const uint32_t *>(sq.raw + (size_t)node * ix.dim)[(size_t)lane * 32u]; }
-    }
     n_pend++;
     if (n_pend == 16) flush();
   }
@@ -696,7 +655,6 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     atomicAdd(&a.counters[0], 1u);
   }
   if (lane == 0) a.status[qi] = (uint32_t)rc;
-  if (PREFETCH && (pf_sink ^ pf_tile ^ pf_row) == 0x9E3779B9u && a.trace_cap == 0xFFFFFFFFu) a.status[qi] = pf_sink;   // (never true: keeps the touch loads alive)
   return rc;
 }
 
