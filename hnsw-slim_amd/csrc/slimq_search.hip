@@ -41,7 +41,9 @@ namespace hs {
 
 static constexpr uint32_t kNoneQ = 0xFFFFFFFFu;
 static constexpr uint32_t kChecked = 0x80000000u;
-static constexpr int kRR = 4;   // re-rank: 16-byte loads in flight per lane
+// re-rank: 16-byte loads in flight per lane and round.  Long codes (d = 768: 12 words) already hold ~115 VGPRs for the estimator's
+// loads, so their re-rank takes twelve at a time for free (d = 768: 4 dependent rounds per flush instead of 12)
+template <int NBLK> struct RerankDepth { static constexpr int v = NBLK >= 8 ? 12 : 4; };
 
 __host__ __device__ inline uint32_t al16(uint32_t x) { return (x + 15u) & ~15u; }
 
@@ -529,6 +531,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const uint32_t steps = ix.dim >> 4;
     // rounds of kRR 16-byte loads in flight per lane (one load per iteration would serialise the HBM latency)
+    constexpr int kRR = RerankDepth<NBLK>::v;
     for (uint32_t r0 = 0; r0 < steps; r0 += kRR) {
       const uint32_t nb = min((uint32_t)kRR, steps - r0);
       float4 buf[kRR];
@@ -572,6 +575,14 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     wave_sync();
   };
 
+#ifdef HS_SLIMQ_DIAG   // diagnostic build (make slimqdiag): shader cycles per phase behind the stats block (tools/slimq_config.py DIAG_EF)
+  uint32_t diag_ph[6] = {0, 0, 0, 0, 0, 0};   // pop + expanded-set | tile wait | estimates | pre-test (set lookups) | insertions | re-rank flush
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long diag_tp = __builtin_amdgcn_s_memtime();
+#define HS_SQ_LAP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); diag_ph[i] += (uint32_t)(t_ - diag_tp); diag_tp = t_; }
+#else
+#define HS_SQ_LAP(i)
+#endif
   while (ps.cur != kNoRank) {
     const uint32_t node = pool_pop<S>(pval, ps, lane);
     const bool seen = set_has(tab, mask, node);
@@ -586,13 +597,19 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     if (lane == 0) set_add(tab, mask, node);                         // :704
     n_set++;
     wave_sync();
+    HS_SQ_LAP(0);
     bool any = false;
     // the scan of one tile of <= 64 neighbours: estimates d (lanes with act), then the buffer updates in adjacency order
     auto scan = [&](bool act, uint32_t c, float d) {
       n_est += __popcll(hs_ballot(act));
       // is_full() can only turn true as the scan proceeds (the last key never grows once the buffer is full), so
       // the pre-test with the state at the start of the tile rejects nothing the sequential scan would accept
+#ifdef HS_SLIMQ_DIAG
+      asm volatile("s_nop 0" : : "v"(d) : "memory");
+      HS_SQ_LAP(2);
+#endif
       unsigned long long pendm = hs_ballot(act && !(d > ps.last) && !set_has(tab, mask, c));
+      HS_SQ_LAP(3);
       while (pendm) {
         const int l = __ffsll((long long)pendm) - 1;
         pendm &= pendm - 1;
@@ -616,6 +633,10 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         const uint32_t slot = base + lane;
         const uint32_t *r = row + (size_t)(slot < ix.tile_stride ? slot : 0) * sq.rec_words;
         const uint4 h = *reinterpret_cast<const uint4 *>(r);
+#ifdef HS_SLIMQ_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HS_SQ_LAP(1);
+#endif
         const bool act = slot < ix.tile_stride && h.w != kNoneQ;
         if (!hs_ballot(act)) break;
         any = true;
@@ -632,11 +653,12 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
         scan(act, c, d);
       }
     }
+    HS_SQ_LAP(4);
     if (!any) continue;   // neighbors == nullptr / size == 0: not reranked either (:708-715)
     n_hops++;
     if (lane == 0) pend[n_pend] = node;
     n_pend++;
-    if (n_pend == 16) flush();
+    if (n_pend == 16) { flush(); HS_SQ_LAP(5); }
   }
   if (rc == ST_DONE) {
     if (n_pend) flush();
@@ -649,7 +671,14 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     }
     if (lane == 0) {
       a.out_counts[qi] = heap_n;
-      if (a.stats) { uint32_t *st = a.stats + (size_t)qi * 4; st[0] = n_hops; st[1] = n_est; st[2] = n_ins; st[3] = n_rev; }
+      if (a.stats) {
+        uint32_t *st = a.stats + (size_t)qi * 4; st[0] = n_hops; st[1] = n_est; st[2] = n_ins; st[3] = n_rev;
+#ifdef HS_SLIMQ_DIAG
+        uint32_t *dg = a.stats + (size_t)a.nq * 4 + (size_t)qi * 16;
+        dg[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0);   // 100 MHz ticks
+        for (int i = 0; i < 6; i++) dg[8 + i] = diag_ph[i];
+#endif
+      }
     }
   } else if (lane == 0) {
     atomicAdd(&a.counters[0], 1u);

@@ -7,6 +7,8 @@ env GRAPH=rq : build the base graph the way the reference's SlimQ strategy does 
                instead of the fp32 bench line's hnswlib graph"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("DIAG_EF"):   # phase stamps of the SlimQ kernel (make -C hnsw-slim_amd slimqdiag) at those ef instead of the sweep
+    os.environ["HS_LIB"] = os.path.join(ROOT, "hnsw-slim_amd", "libhnsw_slim_amd_slimqdiag.so")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
 import torch
@@ -81,6 +83,26 @@ if profile_ef:
     for _ in range(12):
         ix.slimq_search_dev(qt, 10, lab, dd, cnt, None, s); ix.check(s)
     print(f"profile run: {which} ef={profile_ef}, 12 launches of {nq} queries, kernel {ix.last_kernel()}", flush=True)
+    sys.exit(0)
+if os.environ.get("DIAG_EF"):
+    ix.slimq_set_dataset(np.ascontiguousarray(base))
+    lab = torch.empty((nq, 10), dtype=torch.int64, device=dev); dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev); stats = torch.zeros((5 * nq, 4), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    names = ["pop+expanded-set", "tile wait", "estimates", "pre-test (set lookups)", "insertions", "re-rank flush"]
+    for ef in [int(e) for e in os.environ["DIAG_EF"].split(",")]:
+        ix.set_ef(ef)
+        for _ in range(3):
+            ix.slimq_search_dev(qt, 10, lab, dd, cnt, stats, s); ix.check(s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ix.slimq_search_dev(qt, 10, lab, dd, cnt, stats, s); e1.record(); torch.cuda.synchronize()
+        h = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        s4, dg = h[:nq], h[nq:].reshape(nq, 16)
+        wall, pops = dg[:, 0] / 100.0, s4[:, 0] + s4[:, 3]
+        ph = dg[:, 8:14].astype(np.float64)
+        print(f"DIAG {which} ef={ef}: launch {e0.elapsed_time(e1):.3f} ms; query wall us mean {wall.mean():.0f} max {wall.max():.0f}; pops (hops+revisits) mean {pops.mean():.0f} max {pops.max()}; "
+              f"us/pop {wall.sum() / pops.sum():.2f}; est/hop {s4[:, 1].sum() / s4[:, 0].sum():.1f} ins/hop {s4[:, 2].sum() / s4[:, 0].sum():.2f}")
+        print("   shader cycles per pop: " + ", ".join(f"{nm} {ph[:, i].sum() / pops.sum():.0f}" for i, nm in enumerate(names)) + f"; sum {ph.sum() / pops.sum():.0f}", flush=True)
     sys.exit(0)
 ox = Oracle().load_slimq(qp)
 base = np.ascontiguousarray(base)
