@@ -17,9 +17,9 @@
 //     reduction per lane, all of them in one loop.  Output: a small per-query record (delta, vl, k1xsumq, g_add per
 //     cluster, bit planes).  Kept apart so that the search kernel's registers and LDS are sized by the traversal.
 //   * slimq_kernel: the traversal.
-//     - The SearchBuffer (sorted array, capacity ef) lives in registers: rank r in lane r%64, slot r/64, +inf/checked
-//       padding.  Lower-bound position = popcount of a ballot per slot, the memmove = one DPP wave_shr per slot at or
-//       behind the insertion point (wave-uniform branches skip the others), cur_ and the last key are scalars.
+//     - The SearchBuffer (sorted array, capacity ef) lives in registers: rank r in lane r/S, slot r%S, +inf/checked
+//       padding.  Lower-bound position = popcount of a ballot per slot, the memmove = one DPP wave_shr:1 of the last slot +
+//       per-slot selects, the new entry two v_writelane; cur_ and the last key are scalars.
 //     - Level 0 and the upper levels are read from FUSED tiles: slot j of a node's tile is neighbour j's whole RaBitQ
 //       record (16 B of factors + padded/8 B of sign code, 32 B at d=128) with the neighbour id in the header -- one
 //       dependent HBM access per expansion.  One lane per neighbour; the estimator is AND + popcount against the
@@ -66,7 +66,8 @@ size_t slimq_lds_bytes(uint32_t dim, uint32_t padded, uint32_t ncl, uint32_t k, 
 }
 bool slimq_supported(uint32_t pool_cap) { return pool_cap >= 1 && pool_cap <= 1024; }
 
-// ---- expanded-node set: open addressing in LDS, inserts by one lane, lookups by all ---------------------------
+// ---- expanded-node set: open addressing (linear probing) in LDS; the per-lane lookup of the estimate pre-test.  The pop's own
+//      test-and-add reads 64 slots of the probe sequence in one round (slimq_one) ------------------------------------------
 __device__ __forceinline__ uint32_t hash_of(uint32_t id, uint32_t mask) { return (id * 2654435761u) >> 7 & mask; }
 __device__ __forceinline__ bool set_has(const uint32_t *tab, uint32_t mask, uint32_t id) {
   uint32_t h = hash_of(id, mask);
@@ -77,76 +78,90 @@ __device__ __forceinline__ bool set_has(const uint32_t *tab, uint32_t mask, uint
     h = (h + 1) & mask;
   }
 }
-__device__ __forceinline__ void set_add(uint32_t *tab, uint32_t mask, uint32_t id) {
-  uint32_t h = hash_of(id, mask);
-  while (tab[h] != kNoneQ) h = (h + 1) & mask;
-  tab[h] = id;
-}
 
 // ---- SearchBuffer in registers --------------------------------------------------------------------------------
-// Rank r lives in lane r % 64 of slot r / 64.  Ranks at or beyond `size` hold key = +inf, val = 0xFFFFFFFF (reads as
-// "checked"), so neither the position count nor the unchecked scan needs a size mask; entries pushed beyond the
-// capacity are masked by rank < cap in the unchecked scan and can never compare below a candidate that passed
-// is_full().  All control flow here is wave-uniform (scalar branches): the kernel is VALU-issue bound, and a slot
-// that an insertion does not touch costs no vector instruction.
+// Rank r lives in lane r / S, slot r % S (interleaved, as the flat kernel's result set: inserting at rank p is ONE DPP
+// wave_shr:1 of the last slot plus per-slot selects and two v_writelane -- no carries from slot to slot; round 3: the slot-major
+// layout it replaces chained a lane-63 read into the next slot's shift, 1300 shader cycles per insertion at ef = 256,
+// profiles/r03_slimq_sift1m_phases_before.log).  Ranks at or beyond `size` hold key = +inf, val = 0xFFFFFFFF (reads as
+// "checked"), so neither the position count nor the unchecked scan needs a size mask; entries pushed beyond the capacity are
+// masked by rank < cap in the unchecked scan and can never compare below a candidate that passed is_full().
 static constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 template <int S>
 struct PoolState {
   uint32_t size, cap, cur;   // cur = rank of the first unchecked entry (SearchBuffer::cur_), kNoRank when none
   float last;                // key at rank cap-1 once size == cap, else +inf: is_full(d) == (d > last)
+  unsigned long long inr[S]; // lanes whose slot-s rank is below the capacity
 };
+template <int S>
+__device__ __forceinline__ uint32_t pool_at(const uint32_t (&v)[S], uint32_t r) {   // register value at rank r (uniform)
+  const uint32_t l = r / S, sl = r % S;
+  uint32_t x = __builtin_amdgcn_readlane(v[0], l);
+#pragma unroll
+  for (int s = 1; s < S; s++) {
+    const uint32_t t = __builtin_amdgcn_readlane(v[s], l);
+    x = sl == (uint32_t)s ? t : x;
+  }
+  return x;
+}
 // insert(): lower-bound position, shift the tail up by one (:112-119)
 template <int S>
 __device__ __forceinline__ void pool_insert(float (&key)[S], uint32_t (&val)[S], PoolState<S> &p, float d, uint32_t id, int lane) {
   uint32_t pos = 0;
 #pragma unroll
   for (int s = 0; s < S; s++) pos += __popcll(hs_ballot(key[s] < d));
-  const uint32_t sp = pos >> 6, lp = pos & 63;
-  uint32_t carry_k = 0, carry_v = 0;
+  const uint32_t laneS = (uint32_t)lane * S;
+  const float upk = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(key[S - 1]), 0x138, 0xf, 0xf, false));   // wave_shr:1
+  const uint32_t upv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)val[S - 1], 0x138, 0xf, 0xf, false);
 #pragma unroll
-  for (int s = 0; s < S; s++) {
-    if ((uint32_t)s < sp) continue;
-    const uint32_t kb = __float_as_uint(key[s]);
-    uint32_t last_k = 0, last_v = 0;
-    if (s + 1 < S) { last_k = __builtin_amdgcn_readlane(kb, 63); last_v = __builtin_amdgcn_readlane(val[s], 63); }
-    const uint32_t up_k = wave_shr1(carry_k, kb), up_v = wave_shr1(carry_v, val[s]);
-    if ((uint32_t)s == sp) {
-      key[s] = (uint32_t)lane > lp ? __uint_as_float(up_k) : ((uint32_t)lane == lp ? d : key[s]);
-      val[s] = (uint32_t)lane > lp ? up_v : ((uint32_t)lane == lp ? id : val[s]);
-    } else {
-      key[s] = __uint_as_float(up_k);
-      val[s] = up_v;
-    }
-    carry_k = last_k;
-    carry_v = last_v;
+  for (int s = S - 1; s >= 1; s--) {
+    const bool gt = laneS + (uint32_t)s > pos;
+    key[s] = gt ? key[s - 1] : key[s];
+    val[s] = gt ? val[s - 1] : val[s];
+  }
+  {
+    const bool gt = laneS > pos;
+    key[0] = gt ? upk : key[0];
+    val[0] = gt ? upv : val[0];
+  }
+  {   // the new entry: one v_writelane per register, in the slot the rank falls in
+    const uint32_t pl = uni(pos / S), psl = pos % S, du = uni(__float_as_uint(d)), iu = uni(id);
+#pragma unroll
+    for (int s = 0; s < S; s++)
+      if (psl == (uint32_t)s) {
+        key[s] = __uint_as_float(write_lane(__float_as_uint(key[s]), du, pl));
+        val[s] = write_lane(val[s], iu, pl);
+      }
   }
   p.size = min(p.size + 1, p.cap);
   p.cur = min(p.cur, pos);
   if (p.size == p.cap) {
-    const uint32_t sl = (p.cap - 1) >> 6, ll = (p.cap - 1) & 63;
+    uint32_t kb[S];
 #pragma unroll
-    for (int s = 0; s < S; s++)
-      if ((uint32_t)s == sl) p.last = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(key[s]), ll));
+    for (int s = 0; s < S; s++) kb[s] = __float_as_uint(key[s]);
+    p.last = __uint_as_float(pool_at<S>(kb, p.cap - 1));
   }
 }
-// pop(): the entry at cur_, then advance cur_ to the next unchecked rank (:126-134)
+// pop(): the entry at cur_, then advance cur_ to the next unchecked rank (:126-134).  Every rank below cur_ is checked, so the
+// next one is the lowest unchecked rank below the capacity: lowest lane with any such slot, lowest such slot in it.
 template <int S>
 __device__ __forceinline__ uint32_t pool_pop(uint32_t (&val)[S], PoolState<S> &p, int lane) {
-  const uint32_t sc = p.cur >> 6, lc = p.cur & 63;
-  uint32_t id = 0, next = kNoRank;
+  const uint32_t lc = p.cur / S, sc = p.cur % S;
+  const uint32_t id = pool_at<S>(val, p.cur);
+  unsigned long long um[S], any = 0;
 #pragma unroll
   for (int s = 0; s < S; s++) {
-    if ((uint32_t)s < sc || next != kNoRank) continue;
-    if ((uint32_t)s == sc) {
-      id = __builtin_amdgcn_readlane(val[s], lc);
-      if ((uint32_t)lane == lc) val[s] |= kChecked;
-    }
-    unsigned long long m = hs_ballot((int)val[s] >= 0);
-    const int lim = (int)p.cap - 64 * s;               // ranks of this slot below the capacity
-    if (lim <= 0) m = 0ull;
-    else if (lim < 64) m &= (1ull << lim) - 1;
-    if ((uint32_t)s == sc) m &= lc == 63 ? 0ull : ~((2ull << lc) - 1);
-    if (m) next = 64u * s + (uint32_t)__ffsll((long long)m) - 1;
+    if ((uint32_t)s == sc && (uint32_t)lane == lc) val[s] |= kChecked;
+    um[s] = hs_ballot((int)val[s] >= 0) & p.inr[s];
+    any |= um[s];
+  }
+  uint32_t next = kNoRank;
+  if (any) {
+    const uint32_t pl = (uint32_t)__ffsll((long long)any) - 1;
+    uint32_t sl = S - 1;
+#pragma unroll
+    for (int s = S - 2; s >= 0; s--) sl = ((um[s] >> pl) & 1ull) ? (uint32_t)s : sl;
+    next = pl * S + sl;
   }
   p.cur = next;
   return id;
@@ -506,7 +521,10 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
   uint32_t pval[S];
 #pragma unroll
   for (int s = 0; s < S; s++) { pkey[s] = INFINITY; pval[s] = 0xFFFFFFFFu; }
-  PoolState<S> ps{0u, a.pool_cap, kNoRank, INFINITY};
+  PoolState<S> ps;
+  ps.size = 0u; ps.cap = a.pool_cap; ps.cur = kNoRank; ps.last = INFINITY;
+#pragma unroll
+  for (int s = 0; s < S; s++) ps.inr[s] = hs_ballot((uint32_t)(lane * S + s) < a.pool_cap);
   pool_insert<S>(pkey, pval, ps, curd, cur, lane);
   uint32_t heap_n = 0, n_pend = 0, n_set = 0;
   int rc = ST_DONE;
@@ -585,7 +603,23 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
 #endif
   while (ps.cur != kNoRank) {
     const uint32_t node = pool_pop<S>(pval, ps, lane);
-    const bool seen = set_has(tab, mask, node);
+    // expanded-node set, test and (below) add in ONE LDS round: the 64 lanes read the 64 slots of the probe sequence from the
+    // node's home slot on; the id is present iff it shows before the first empty slot, and that slot is where linear probing
+    // puts it (so the per-lane lookups of the pre-test below, which walk the same sequence, find it)
+    bool seen = false;
+    uint32_t free_slot = 0;
+    for (uint32_t h0 = hash_of(node, mask);; h0 = (h0 + 64u) & mask) {
+      const uint32_t sl = (h0 + (uint32_t)lane) & mask;
+      const uint32_t v = tab[sl];
+      const unsigned long long m_eq = hs_ballot(v == node), m_emp = hs_ballot(v == kNoneQ);
+      if (m_emp) {
+        const uint32_t e = (uint32_t)__ffsll((long long)m_emp) - 1;
+        seen = (m_eq & ((1ull << e) - 1ull)) != 0ull;
+        free_slot = (h0 + e) & mask;
+        break;
+      }
+      if (m_eq) { seen = true; break; }
+    }
     if (DBG && a.trace && lane == 0 && n_tr + 1 < a.trace_cap) {
       a.trace[(size_t)qi * a.trace_cap + n_tr] = node | (seen ? kChecked : 0u);
       a.trace[(size_t)qi * a.trace_cap + n_tr + 1] = ps.size;
@@ -593,8 +627,7 @@ __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs
     n_tr += 2;
     if (seen) { n_rev++; continue; }                                 // :700-702
     if (__builtin_expect((n_set + 1) * 4 > a.hash_slots * 3, 0)) { rc = ST_OVERFLOW; break; }
-    wave_sync();
-    if (lane == 0) set_add(tab, mask, node);                         // :704
+    if (lane == 0) tab[free_slot] = node;                            // :704
     n_set++;
     wave_sync();
     HS_SQ_LAP(0);
