@@ -1,7 +1,8 @@
 // lean_search.hip -- the one-query-per-wavefront search kernel rebuilt for residency: same algorithm, same exactness contract
-// and the same visited set / candidate heap as beam_search.hip's fast kernel, but sized so that SIX wavefronts fit a SIMD
-// (<= 80 VGPRs, ~6.6 KB of LDS per query) instead of four -- the round-2 measurements show the search is bound by
-// how many independent gather streams the chip has in flight, not by arithmetic:
+// and the same visited set / candidate heap as beam_search.hip's fast kernel, but sized so that FIVE wavefronts fit a SIMD
+// (90-95 VGPRs as built, resource_usage.txt; ~6.6 KB of LDS per query) instead of four -- the round-2 measurements
+// show the search is bound by how many independent gather streams the chip has in flight, not by arithmetic.  Since round 3 the
+// flat kernel (flat_search.hip) is the default on the shapes this one serves; it stays for HS_KERNEL=lean A/B runs and its tests:
 //   * distances: 8 lanes per row, 8 rows per pass; a lane owns TWO of the sixteen AVX-512 lane accumulators and loads 8 bytes
 //     of every 64-byte step, so a pass keeps the same bytes in flight per row with half the buffer registers, and the L2 recipe
 //     (rounded subtract, multiply, add) is exactly one v_pk_add / v_pk_mul / v_pk_add per step; values go straight to the lane

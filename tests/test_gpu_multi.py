@@ -254,3 +254,32 @@ def test_index_from_host_arrays_equals_index_from_file(hs, slim_file):
         assert np.array_equal(rc["labels"], rd["labels"]) and rc["dists"].tobytes() == rd["dists"].tobytes() and np.array_equal(rc["stats"], rd["stats"])
     with pytest.raises(hs.HsError):
         hs.Index.from_arrays(hs.HS_KIND_SLIM, hs.HS_METRIC_L2, s["rows"], s["level"], s["lists"], 10 ** 9, s["maxlevel"])
+
+
+def test_lean_kernel_with_more_than_64k_of_lds(hs, tmp_path):
+    """A user candidate-heap capacity that takes the lean kernel's LDS request beyond 64 KiB (lean_search.hip sets
+    hipFuncAttributeMaxDynamicSharedMemorySize for it): the launch must succeed and answer like the default kernel."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from hsutil import load_product, mixture
+hs = load_product()
+q = mixture(100, 128, 32, n_clusters=32, integer=True)
+ix = hs.Index(sys.argv[2] + "/s.bin", hs.HS_KIND_SLIM, 128)
+ix.set_ef(64); ix.set_capacity(int(sys.argv[4]), 0)
+r = ix.search_ids(q, 10, want_dists=True, want_stats=True)
+np.savez(sys.argv[3], l=np.sort(r["labels"], 1), d=np.sort(r["dists"], 1), s=r["stats"][:, :3], k=np.array([ix.last_kernel()]))
+'''
+    wf = str(tmp_path / "w.py")
+    open(wf, "w").write(code)
+    base = mixture(8000, 128, 31, n_clusters=32, integer=True)
+    hs.build_hnsw(base, str(tmp_path / "h.bin"), M=16, ef_construction=80, threads=8)
+    hs.convert_slim(str(tmp_path / "h.bin"), str(tmp_path / "s.bin"), 128, threads=8)
+    res = {}
+    for tag, env, cap in (("default", {}, "0"), ("lean_big", {"HS_KERNEL": "lean", "HS_LEAN_MIN_EF": "1", "HS_ORDER": "0"}, "9000")):
+        of = str(tmp_path / f"{tag}.npz")
+        subprocess.check_call([sys.executable, wf, ROOT, str(tmp_path), of, cap], env=dict(os.environ, **env))
+        res[tag] = np.load(of)
+    assert str(res["lean_big"]["k"][0]) == "hs::lean_kernel" and str(res["default"]["k"][0]) == "hs::flat_kernel"
+    for key in ("l", "d", "s"):
+        assert np.array_equal(res["default"][key], res["lean_big"][key]), key
