@@ -483,10 +483,11 @@ __device__ int strict_beam(const DevIndex &ix, const SearchArgs &a, int level, b
 template <int METRIC>
 __device__ void search_one_strict(const DevIndex &ix, const SearchArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
-  const StrictLds L = strict_layout(ix.dim, a.ef, a.cand_cap, a.hash_slots);
+  const StrictLds L = strict_layout(ix.dim, a.ef, a.fb_cand ? 0u : a.cand_cap, a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
   Pair *top = reinterpret_cast<Pair *>(smem + L.off_top);
-  Pair *cand = reinterpret_cast<Pair *>(smem + L.off_cand);
+  Pair *cand = a.fb_cand ? reinterpret_cast<Pair *>(a.fb_cand) + (size_t)blockIdx.x * a.cand_cap   // last-resort pass: the heap in global memory
+                         : reinterpret_cast<Pair *>(smem + L.off_cand);
   uint32_t *hash = reinterpret_cast<uint32_t *>(smem + L.off_hash);
   uint32_t *nid = reinterpret_cast<uint32_t *>(smem + L.off_nid);
   float *nd = reinterpret_cast<float *>(smem + L.off_nd);
@@ -1198,9 +1199,15 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   float lo = FLT_MAX, hi = -FLT_MAX;
   auto key_of = [&](uint32_t i) -> float { return __uint_as_float(entry[i].y); };
-  for (uint32_t i = t; i < nq; i += kOrderThreads) {
-    const float d = key_of(i);
-    if (d == d && fabsf(d) <= FLT_MAX) { lo = fminf(lo, d); hi = fmaxf(hi, d); }
+  // (every pass over the entries takes eight loads per thread in flight: one at a time, the three passes were 30 us of dependent
+  //  global-memory latency for 10k queries)
+  constexpr uint32_t U = 8;
+  for (uint32_t b0 = t; b0 < nq; b0 += kOrderThreads * U) {
+    float dv[U];
+#pragma unroll
+    for (uint32_t j = 0; j < U; j++) { const uint32_t i = b0 + j * kOrderThreads; dv[j] = i < nq ? key_of(i) : __builtin_nanf(""); }
+#pragma unroll
+    for (uint32_t j = 0; j < U; j++) { const float d = dv[j]; if (d == d && fabsf(d) <= FLT_MAX) { lo = fminf(lo, d); hi = fmaxf(hi, d); } }
   }
   for (int off = 32; off > 0; off >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, off));
@@ -1217,7 +1224,13 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
     const float x = (hi - fminf(fmaxf(d, lo), hi)) * scale;
     return min((uint32_t)x, kOrderBins - 1);
   };
-  for (uint32_t i = t; i < nq; i += kOrderThreads) atomicAdd(&bins[bin_of(key_of(i))], 1u);
+  for (uint32_t b0 = t; b0 < nq; b0 += kOrderThreads * U) {
+    float dv[U];
+#pragma unroll
+    for (uint32_t j = 0; j < U; j++) { const uint32_t i = b0 + j * kOrderThreads; dv[j] = i < nq ? key_of(i) : 0.f; }
+#pragma unroll
+    for (uint32_t j = 0; j < U; j++) if (b0 + j * kOrderThreads < nq) atomicAdd(&bins[bin_of(dv[j])], 1u);
+  }
   __syncthreads();
   // exclusive prefix sums of the bins: kOrderPer consecutive bins per thread, wave scan, then the wave totals
   uint32_t v[kOrderPer], sum = 0;
@@ -1235,7 +1248,13 @@ __global__ void __launch_bounds__(kOrderThreads) order_kernel(const uint4 *entry
   __syncthreads();
   for (uint32_t j = 0; j < kOrderPer; j++) { bins[kOrderPer * t + j] = run; run += v[j]; }
   __syncthreads();
-  for (uint32_t i = t; i < nq; i += kOrderThreads) order[atomicAdd(&bins[bin_of(key_of(i))], 1u)] = i;
+  for (uint32_t b0 = t; b0 < nq; b0 += kOrderThreads * U) {
+    float dv[U];
+#pragma unroll
+    for (uint32_t j = 0; j < U; j++) { const uint32_t i = b0 + j * kOrderThreads; dv[j] = i < nq ? key_of(i) : 0.f; }
+#pragma unroll
+    for (uint32_t j = 0; j < U; j++) { const uint32_t i = b0 + j * kOrderThreads; if (i < nq) order[atomicAdd(&bins[bin_of(dv[j])], 1u)] = i; }
+  }
 }
 hipError_t launch_order(const uint4 *entry, uint32_t *order, uint32_t nq, hipStream_t stream) {
   static_assert(kOrderBins == kOrderPer * kOrderThreads, "whole bins per thread in the prefix step");
@@ -1254,7 +1273,7 @@ hipError_t launch_strict_l2(const DevIndex &ix, const SearchArgs &a, size_t lds,
   return launch(strict_kernel<METRIC_L2>, ix, a, lds, stream);
 }
 hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
-  const size_t lds = strict_lds_bytes(ix.dim, a.ef, a.cand_cap, a.hash_slots);
+  const size_t lds = strict_lds_bytes(ix.dim, a.ef, a.fb_cand ? 0u : a.cand_cap, a.hash_slots);
   return ix.metric == METRIC_L2 ? launch_strict_l2(ix, a, lds, stream) : launch_strict_ip(ix, a, lds, stream);
 }
 hipError_t launch_fast(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {

@@ -97,6 +97,8 @@ struct hs_index {
     DevBuf<uint32_t> prep;              // SlimQ: per-query preparation records
     DevBuf<uint32_t> status, counters;  // counters: 3 passes x 4 {visited overflow, candidate overflow, tie hazard, tier-2 spills}
     DevBuf<uint32_t> entry, order;      // two-launch fast pass: level-0 entries (nq x 4 words) and the start order
+    DevBuf<uint32_t> fb;                // last-resort pass: kFbGrid x (candidate heap + tier-2 visited set)
+    uint32_t oflip = 0;
     size_t last_nq = 0;
     // hs_search_batch_async: device staging of the queries and outputs of the call in flight on this stream
     DevBuf<float> aq, adist;
@@ -143,7 +145,9 @@ struct Shape {
   uint32_t fb_cand_cap, fb_hash_slots;  // last-resort pass (one workgroup per CU, whole LDS)
 };
 static constexpr size_t kLdsPerCU = 160 * 1024;
-static constexpr size_t kFallbackLds = 64 * 1024;   // LDS of the last-resort pass (strict kernel)
+// Last-resort pass (strict kernel): a few workgroups, each with a small visited hash in LDS and its candidate heap + a large
+// tier-2 visited set in its own region of global memory (engine.hpp fb_cand / fb_spill): 24 MiB per stream, any query fits.
+static constexpr uint32_t kFbGrid = 32, kFbCand = 32768, kFbSpill = 131072, kFbHash = 2048;
 static constexpr uint32_t kLeanMinEfContinuous = 192;   // continuous data: the fast kernel's flat start never materialises a heap and wins below this
 static constexpr uint32_t kLeanMinEf = 64;    // from here upwards the lean kernel (keys-only result set, 95 VGPRs: 5 waves per SIMD without scratch, smaller LDS share)
                                               // is the faster one on its shapes (L2, d = 96 / 128): ef=70 -5 % single launch / +4 % on a 32k call (0.41 of the HBM peak),
@@ -204,22 +208,12 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
   while (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU && s.cand_cap > 128) s.cand_cap = (s.cand_cap / 2 + 1) & ~1u;
   if (strict_lds_bytes(dim, s.ef, s.cand_cap, s.hash_slots) > kLdsPerCU)
     return fail(HS_ERR_CAPACITY, "ef/dim do not fit the 160 KiB LDS of one CU");
-  // last resort: the largest power-of-two hash that leaves at least as many bytes to the candidate heap, within kFallbackLds.
-  // (Not the whole CU: this pass is launched with every batch and is normally empty -- a workgroup that asks for all 160 KiB
-  // waits until a CU has drained completely, which with several batches in flight held every batch's stream for ~0.5 ms,
-  // profiles/r03_kernel_stats_pipelined.csv; beyond its LDS share the pass continues in the tier-2 regions like every other.)
-  const size_t fixed = strict_lds_bytes(dim, s.ef, 0, 0);
-  for (size_t fb_total : {std::min<size_t>(kLdsPerCU, std::max<size_t>(kFallbackLds, fixed + 16 * 1024)), kLdsPerCU}) {
-    const size_t rem = fb_total - fixed;
-    uint32_t hs_slots = 256;
-    while ((size_t)hs_slots * 2 * 4 <= rem / 2) hs_slots *= 2;
-    s.fb_hash_slots = std::max(hs_slots, s.hash_slots);
-    if (fixed + (size_t)s.fb_hash_slots * 4 + 1024 > fb_total) continue;   // (a first-pass hash larger than this share: whole CU)
-    const size_t cand_bytes = fb_total - fixed - (size_t)s.fb_hash_slots * 4;
-    s.fb_cand_cap = (uint32_t)((cand_bytes / 8) & ~size_t(1));
-    break;
-  }
-  if (s.fb_cand_cap < s.cand_cap) { s.fb_cand_cap = s.cand_cap; s.fb_hash_slots = s.hash_slots; }
+  // last resort (see kFbGrid): LDS = query + result array + a kFbHash-slot visited hash; everything else in global memory.
+  // (It goes out with every batch and is normally empty; when it asked for 64 KiB -- before that for a whole CU -- it waited 0.56 ms
+  // on average for that much LDS to drain behind the other streams' launches, profiles/r03_kernel_stats_pipelined.csv.)
+  s.fb_cand_cap = kFbCand;
+  s.fb_hash_slots = kFbHash;
+  while (strict_lds_bytes(dim, s.ef, 0, s.fb_hash_slots) > kLdsPerCU && s.fb_hash_slots > 256) s.fb_hash_slots >>= 1;
   return HS_OK;
 }
 
@@ -842,21 +836,14 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     }
     fast_scratch(false);
   }
-  // Both re-run passes are normally empty (a launch that scans the statuses and exits), so they share one launch whenever
-  // the whole-CU pass exists: a batch is then two kernel launches, not three.
-  const bool big_pass = sh.fb_cand_cap > sh.cand_cap || sh.fb_hash_slots > sh.hash_slots;
-  // pass 1: tie queries whose insertion log did not fit (normally none) -> strict kernel
-  if ((fast || lean || flatk) && !big_pass) {
-    a.select_mask = 1u << ST_HAZARD; a.grid = (uint32_t)std::min<size_t>(nq, 256); a.cand_cap = sh.cand_cap;
-    a.counters = w->counters.p + 4; a.pass_id = 1;
-    HIP_TRY(launch_strict(ix->dev, a, stream));
-  }
-  // pass 2: queries that outgrew their scratch (and, see above, pass 1's) -> strict kernel with a whole CU's LDS each
-  if (big_pass) {
-    // few workgroups: each needs a whole CU's LDS, i.e. a CU drained of every other wave before it can start -- with
-    // several batches in flight a wide grid of them stalls the stream even when (as usual) no query is flagged
-    a.select_mask = (1u << ST_OVERFLOW) | ((fast || lean || flatk) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, 16);
-    a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots;
+  // Re-run pass (normally empty: a launch that scans the statuses and exits): tie queries whose insertion log did not fit
+  // (ST_HAZARD) and queries that outgrew their scratch (ST_OVERFLOW) -> strict kernel, a few workgroups, candidate heap and a
+  // large tier-2 visited set per workgroup in global memory (kFbGrid).
+  {
+    a.select_mask = (1u << ST_OVERFLOW) | ((fast || lean || flatk) ? (1u << ST_HAZARD) : 0u); a.grid = (uint32_t)std::min<size_t>(nq, kFbGrid);
+    HIP_TRY(w->fb.ensure((size_t)kFbGrid * ((size_t)kFbCand * 2 + kFbSpill)));
+    a.cand_cap = sh.fb_cand_cap; a.hash_slots = sh.fb_hash_slots; a.vis_bits = 0; a.hash_fill_shift = 0;
+    a.fb_cand = w->fb.p; a.fb_spill = w->fb.p + (size_t)kFbGrid * kFbCand * 2; a.spill_slots = kFbSpill;
     a.counters = w->counters.p + 8; a.pass_id = 2;
     HIP_TRY(launch_strict(ix->dev, a, stream));
   }

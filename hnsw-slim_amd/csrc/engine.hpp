@@ -64,6 +64,11 @@ struct SearchArgs {
   uint32_t phase;
   uint4 *entry;
   const uint32_t *order;
+  // Last-resort pass (strict kernel, pass_id 2): candidate heap and tier-2 visited set in per-WORKGROUP regions of global memory
+  // (cand_cap entries / spill_slots words each, indexed by blockIdx.x), so that the launch -- which goes out with every batch and is
+  // normally empty -- asks for a dozen KiB of LDS instead of a drained CU.  Null in every other pass.
+  void *fb_cand;
+  uint32_t *fb_spill;
   // Flat kernel (flat_search.hip): visited set of fl_nb 16-byte buckets; bucket = h mod fl_nb, remainder = h div fl_nb =
   // umulhi(h, fl_mul) >> fl_sh (exact for h < 2^vis_bits; remainders fit 15 bits)
   uint32_t fl_nb, fl_mul, fl_sh;

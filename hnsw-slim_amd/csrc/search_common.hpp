@@ -29,7 +29,7 @@ __device__ __forceinline__ void vis_init(Visited &v, const SearchArgs &a, uint32
   v.t1 = lds_tab;
   v.slots1 = a.hash_slots;
   v.limit1 = a.hash_slots - (a.hash_slots >> (a.hash_fill_shift ? a.hash_fill_shift : 2));   // 75 % by default, 87.5 % for the lean kernel
-  v.t2 = a.spill ? a.spill + (size_t)qi * a.spill_stride : nullptr;
+  v.t2 = a.fb_spill ? a.fb_spill + (size_t)blockIdx.x * a.spill_slots : (a.spill ? a.spill + (size_t)qi * a.spill_stride : nullptr);
   v.slots2 = a.spill_slots;
   v.limit2 = a.spill_slots - (a.spill_slots >> 2);
   v.n1 = v.n2 = 0;
