@@ -1052,7 +1052,8 @@ hs_status hs_slimq_set_tconst(hs_index *ix, double t_const) {
 }
 double hs_slimq_get_tconst(const hs_index *ix) { return ix && ix->info.kind == HS_KIND_SLIMQ ? ix->sq.t_const : 0.0; }
 
-static constexpr uint32_t kSlimQMaxHash = 16384;  // 64 KiB of LDS: the second pass's expanded-node set
+static constexpr uint32_t kSlimQMaxHash = 16384;  // largest expanded-node set in LDS (64 KiB)
+static constexpr uint32_t kSlimQFbHash = 65536, kSlimQFbGrid = 64;  // second pass: the set in global memory, 256 KiB per workgroup
 
 hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, size_t k, uint64_t *d_out_labels,
                                     float *d_out_dists, uint32_t *d_out_counts, uint32_t *d_stats, void *stream_) {
@@ -1102,8 +1103,9 @@ hs_status hs_slimq_search_batch_dev(hs_index *ix, const float *d_queries, size_t
   } else {
     HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
   }
-  if (a.hash_slots < kSlimQMaxHash) {
-    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, 64); a.hash_slots = kSlimQMaxHash;
+  {
+    HIP_TRY(w->fb.ensure((size_t)kSlimQFbGrid * kSlimQFbHash));
+    a.select_mask = 1u << ST_OVERFLOW; a.grid = (uint32_t)std::min<size_t>(nq, kSlimQFbGrid); a.hash_slots = kSlimQFbHash; a.fb_tab = w->fb.p;
     a.counters = w->counters.p + 8;
     HIP_TRY(launch_slimq(ix->dev, ix->sq, a, stream));
   }

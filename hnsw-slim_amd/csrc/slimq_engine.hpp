@@ -24,7 +24,9 @@ struct SlimQArgs {
   const float *queries;   // nq x dim (device)
   uint32_t nq, k;
   uint32_t pool_cap;      // SearchBuffer capacity = ef_ (setEf, hnswalg_slimq.h:346-349)
-  uint32_t hash_slots;    // expanded-node set (LDS), power of two
+  uint32_t hash_slots;    // expanded-node set, power of two: in LDS, or -- second pass -- in global memory:
+  uint32_t *fb_tab;       // nullable; hash_slots words per WORKGROUP (indexed by blockIdx.x): the always-issued, normally empty
+                          // second pass then asks for no more LDS than the first one (it waited for 64 KiB to drain)
   uint32_t select_mask, grid;
   uint64_t *out_labels;   // nq x k, the reference's heap-array order (hnswalg_slimq.h:1921-1923); ~0 beyond count
   float *out_dists;       // nq x k exact distances of those entries

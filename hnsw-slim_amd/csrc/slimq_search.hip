@@ -411,11 +411,11 @@ hipError_t launch_slimq_prep(const DevSlimQ &sq, uint32_t dim, int metric, const
 template <int METRIC, int S, int NBLK, bool DBG = false>
 __device__ int slimq_one(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, const uint32_t qi, unsigned char *smem) {
   const int lane = threadIdx.x;
-  const SlimQLds L = slimq_layout(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
+  const SlimQLds L = slimq_layout(ix.dim, sq.padded, sq.ncl, a.k, a.fb_tab ? 0u : a.hash_slots);
   float *qv = reinterpret_cast<float *>(smem + L.off_q);
   uint64_t *planes_lds = reinterpret_cast<uint64_t *>(smem + L.off_planes);
   float *gadd = reinterpret_cast<float *>(smem + L.off_red);
-  uint32_t *tab = reinterpret_cast<uint32_t *>(smem + L.off_hash);
+  uint32_t *tab = a.fb_tab ? a.fb_tab + (size_t)blockIdx.x * a.hash_slots : reinterpret_cast<uint32_t *>(smem + L.off_hash);
   Pair *heap = reinterpret_cast<Pair *>(smem + L.off_heap);
   uint32_t *pend = reinterpret_cast<uint32_t *>(smem + L.off_pend);
   float *pd = reinterpret_cast<float *>(smem + L.off_pd);
@@ -759,7 +759,7 @@ static hipError_t launch_ms(const DevIndex &ix, const DevSlimQ &sq, const SlimQA
   return launch_k(slimq_kernel<METRIC, 16, NBLK>, ix, sq, a, lds, stream);
 }
 hipError_t launch_slimq(const DevIndex &ix, const DevSlimQ &sq, const SlimQArgs &a, hipStream_t stream) {
-  const size_t lds = slimq_lds_bytes(ix.dim, sq.padded, sq.ncl, a.k, a.hash_slots);
+  const size_t lds = slimq_lds_bytes(ix.dim, sq.padded, sq.ncl, a.k, a.fb_tab ? 0u : a.hash_slots);
   if (a.trace)   // the parity/debug entry: one generic configuration that records the SearchBuffer events
     return ix.metric == METRIC_L2 ? launch_k(slimq_kernel<METRIC_L2, 16, 0, true>, ix, sq, a, lds, stream)
                                   : launch_k(slimq_kernel<METRIC_IP, 16, 0, true>, ix, sq, a, lds, stream);

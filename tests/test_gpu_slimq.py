@@ -231,3 +231,24 @@ def test_slimq_file_rewritten_by_python(env):
     b, _ = check(P, O, p2, base, q, 0, 10, (40,))
     ra, rb = a.slimq_search(q, 10, want_stats=True), b.slimq_search(q, 10, want_stats=True)
     assert np.array_equal(ra["labels"], rb["labels"]) and ra["dists"].tobytes() == rb["dists"].tobytes() and np.array_equal(ra["stats"], rb["stats"])
+
+
+def test_slimq_second_pass_with_starved_expanded_set(env):
+    """hs_set_capacity(hash_slots = 32): the first pass's expanded-node set overflows on most queries (ST_OVERFLOW) and the second
+    pass -- the set per workgroup in global memory, capi.cpp kSlimQFbHash -- must give the oracle's answers."""
+    P, O, tmp = env
+    x = sift_like(5000 + 200, 128, seed=17, n_clusters=32)
+    base, q = x[:5000], x[5000:]
+    path = build(P, tmp, "d128_starved", base, 0, 8)
+    ix = P.Index(path, P.HS_KIND_SLIMQ, 128)
+    ix.slimq_set_dataset(base)
+    ox = O.load_slimq(path)
+    ix.set_capacity(0, 32)
+    for ef in (64, 300):
+        ix.set_ef(ef)
+        ox.set(ef, ix.slimq_tconst(), base)
+        got, ref = ix.slimq_search(q, 10, want_stats=True), ox.search(q, 10, threads=8)
+        assert (ref["counters"][:, 0] > 24).mean() > 0.5, "premise: most queries expand more nodes than 75 % of 32 slots"
+        assert np.array_equal(got["stats"].astype(np.uint64), ref["counters"]), ef
+        assert np.array_equal(got["labels"], ref["labels"]), ef
+        assert np.array_equal(got["dists"].view(np.uint32), ref["dists"].view(np.uint32)), ef
