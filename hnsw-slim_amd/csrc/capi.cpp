@@ -84,7 +84,6 @@ struct hs_index {
   const char *last_kernel = "";           // the kernel that served pass 0 of the most recent search call (hs_last_kernel)
   // patching (hs_index_patch): a Slim index loaded with max_elements > count keeps its host image and has row capacity
   std::unique_ptr<SlimGraph> host_slim;
-  bool integer_data = false;   // every sampled vector component is an integer (set at upload; steers the kernel choice)
   size_t cap_rows = 0;
   DevIndex dev{};
   DevBuf<float> vec;
@@ -148,10 +147,7 @@ static constexpr size_t kLdsPerCU = 160 * 1024;
 // Last-resort pass (strict kernel): a few workgroups, each with a small visited hash in LDS and its candidate heap + a large
 // tier-2 visited set in its own region of global memory (engine.hpp fb_cand / fb_spill): 24 MiB per stream, any query fits.
 static constexpr uint32_t kFbGrid = 32, kFbCand = 32768, kFbSpill = 131072, kFbHash = 2048;
-static constexpr uint32_t kLeanMinEfContinuous = 192;   // continuous data: the fast kernel's flat start never materialises a heap and wins below this
-static constexpr uint32_t kLeanMinEf = 64;    // from here upwards the lean kernel (keys-only result set, 95 VGPRs: 5 waves per SIMD without scratch, smaller LDS share)
-                                              // is the faster one on its shapes (L2, d = 96 / 128): ef=70 -5 % single launch / +4 % on a 32k call (0.41 of the HBM peak),
-                                              // ef=128 -13 % / +13 %, ef=160 -25 % / +34 %; at ef=48 the fast kernel with the flat start still wins (profiles/r02_ordered_pass_experiments.log)
+static constexpr uint32_t kLeanMinEf = 64;    // HS_KERNEL=lean: the lean kernel answers from this ef upwards (HS_LEAN_MIN_EF overrides), the fast kernel below
 static constexpr uint32_t kSpillSlots = 8192;  // 32 KiB per query of tier-2 visited set
 static constexpr uint32_t kCand2Cap = 4096;    // 32 KiB per query of tier-2 candidate heap
 static constexpr uint32_t kLogCap = 4096;      // 32 KiB per query: result-set insertion log (tie replay)
@@ -327,20 +323,6 @@ static hs_status upload_small(hs_index *ix, const PackedIndex &p) {
 
 static hs_status upload(hs_index *ix, const PackedIndex &p) {
   HIP_TRY(hipSetDevice(ix->device));
-  // Integer-valued vectors (SIFT-like) give integer distances, i.e. candidates that tie: the flat start of the fast kernel
-  // then falls back to the heap in a quarter of the queries and the lean kernel is the faster one from ef = 64; on
-  // continuous data the flat start never leaves its path and wins up to ef = 128 (DEEP-10M: 8.8 vs 7.9 M q/s at ef=64).
-  // A strided sample of the rows decides which regime this index is in (kernel choice only: every kernel is exact on both).
-  {
-    bool integral = p.n > 0 && p.vec.size() >= p.n * p.dim;   // (a SlimQ index carries no fp32 rows here)
-    const size_t step = std::max<size_t>(p.n / 4096, 1);
-    for (size_t i = 0; i < p.n && integral; i += step)
-      for (size_t j = 0; j < p.dim; j++) {
-        const float v = p.vec[i * p.dim + j];
-        if (!(v == std::floor(v)) || std::fabs(v) > 16777216.f) { integral = false; break; }
-      }
-    ix->integer_data = integral;
-  }
   const size_t cap = std::max(ix->cap_rows, p.n);
   HIP_TRY(upload_cap(ix->vec, p.vec, cap * p.dim));
   // level-0 adjacency tiles: node i's ids padded with 0xFFFFFFFF to a fixed, 64-byte-multiple stride
@@ -759,15 +741,17 @@ static hs_status search_dev_group(hs_index *ix, const float *d_q, size_t nq, siz
     a.hash_slots = on ? fast_hash : sh.hash_slots;
     a.vis_bits = on ? sh.q_bits : 0;
   };
-  // The lean kernel answers from HS_LEAN_MIN_EF upwards (diagnostic knob; default: see kLeanMinEf)
-  static const uint32_t lean_min_ef = getenv("HS_LEAN_MIN_EF") ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
-  static const bool lean_forced = getenv("HS_LEAN_MIN_EF") != nullptr;   // the parity tests force it on every shape it supports
-  const uint32_t lean_from = lean_forced ? lean_min_ef : (ix->integer_data ? kLeanMinEf : kLeanMinEfContinuous);
-  const bool lean = fast && sh.ef >= lean_from && lean_supported(ix->dev, sh.ef, (uint32_t)k) && (lean_forced || lean_preferred(ix->dev)) &&
-                    lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots) <= kLdsPerCU;
-  // The flat kernel (lazy candidate heap, flat_search.hip) answers every bare index it supports; HS_KERNEL=lean|fast selects the
-  // older kernels for A/B runs and for their parity tests, HS_KERNEL=flat forces it.
+  // The flat kernel (lazy candidate heap, flat_search.hip) answers every bare index it supports.  The older kernels run where it
+  // does not (filters, delete marks, threshold_level > 0, dim % 16 != 0, ef > 512: fast / strict) and when asked for by name:
+  // HS_KERNEL=lean|fast for A/B runs and their parity tests (HS_LEAN_MIN_EF=<ef> asks for the lean kernel from that ef upwards),
+  // HS_KERNEL=flat forces the flat kernel.  No property of the DATA enters the choice (until round 2 a strided sample of the rows
+  // -- "integer-valued?" -- moved the lean / fast threshold).
   static const char *kernel_env = getenv("HS_KERNEL");
+  static const bool lean_forced = getenv("HS_LEAN_MIN_EF") != nullptr;
+  static const uint32_t lean_min_ef = lean_forced ? (uint32_t)atoi(getenv("HS_LEAN_MIN_EF")) : kLeanMinEf;
+  static const bool lean_asked = lean_forced || (kernel_env && !strcmp(kernel_env, "lean"));
+  const bool lean = lean_asked && fast && sh.ef >= lean_min_ef && lean_supported(ix->dev, sh.ef, (uint32_t)k) &&
+                    lean_lds_bytes((uint32_t)ix->info.dim, sh.ef, sh.l_cand_cap, sh.q_bits ? sh.q_hash_slots : sh.l_hash_slots) <= kLdsPerCU;
   static const bool flatk_off = kernel_env && (!strcmp(kernel_env, "lean") || !strcmp(kernel_env, "fast"));
   const FlatPlan fp = plan_flat(ix, sh.ef, nq);
   const bool flatk = !flatk_off && !lean_forced && fast && fp.ok && flatk_supported(ix->dev, sh.ef, (uint32_t)k);

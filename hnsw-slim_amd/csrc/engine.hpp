@@ -89,7 +89,6 @@ hipError_t launch_strict(const DevIndex &ix, const SearchArgs &a, hipStream_t st
 hipError_t launch_order(const uint4 *entry, uint32_t *order, uint32_t nq, hipStream_t stream);
 // Lean kernel (lean_search.hip): the fast kernel's algorithm with a keys-only result set (no ids, no LDS staging of the merge).
 bool lean_supported(const DevIndex &ix, uint32_t ef, uint32_t k);
-bool lean_preferred(const DevIndex &ix);   // shapes on which it beats the fast kernel at large ef (compile-time dims)
 size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots);
 hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stream);
 // Flat kernel (flat_search.hip): lazy candidate heap -- replayed from the insertion log only when its layout decides a pop.

@@ -532,7 +532,6 @@ bool lean_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
 }
 // Where it is the better kernel: measured only on the shapes it is compiled for with a compile-time dim (L2, d = 96 / 128); every
 // other shape would take its runtime-dim distance loop against the fast kernel's compiled-in one.
-bool lean_preferred(const DevIndex &ix) { return ix.metric == METRIC_L2 && (ix.dim == 128 || ix.dim == 96); }
 size_t lean_lds_bytes(uint32_t dim, uint32_t ef, uint32_t cand_cap, uint32_t hash_slots) { return lean_layout(dim, ef, cand_cap, hash_slots).total; }
 hipError_t launch_lean_l2(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) { return lean_launch_s<METRIC_L2>(ix, a, stream); }
 hipError_t launch_lean(const DevIndex &ix, const SearchArgs &a, hipStream_t stream) {
