@@ -252,3 +252,20 @@ def test_slimq_second_pass_with_starved_expanded_set(env):
         assert np.array_equal(got["stats"].astype(np.uint64), ref["counters"]), ef
         assert np.array_equal(got["labels"], ref["labels"]), ef
         assert np.array_equal(got["dists"].view(np.uint32), ref["dists"].view(np.uint32)), ef
+
+
+def test_slimq_on_the_references_own_graph_pipeline(env):
+    """The index built the way hnsw_slimq_strategy.h:106-128 builds it -- rabitqlib-style HNSW (M = 32: level-0 lists of up to 64
+    ids, the widest fused tiles) + SlimQ's own PruneByHeuristic -- searched on the GPU and by the oracle: L2 and inner product."""
+    P, O, tmp = env
+    for metric, d, seed in ((0, 128, 23), (1, 64, 29)):
+        x = sift_like(5000 + 200, d, seed=seed, n_clusters=24, integer=False)
+        if metric == 1:
+            x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+        base, q = np.ascontiguousarray(x[:5000]), np.ascontiguousarray(x[5000:])
+        h, s, sq = (str(tmp / f"rq{metric}.{e}") for e in ("hnsw", "slim", "slimq"))
+        P.build_rabitq_hnsw(base, h, metric=metric, M=32, ef_construction=128, seed=100, threads=8)
+        P.convert_slimq_graph(h, s, d, metric=metric, threads=8)
+        P.convert_slimq(s, metric, d, kmeans(base, 8), sq, threads=8)
+        ix, _ = check(P, O, sq, base, q, metric, 10, (16, 100, 300))
+        assert ix.info()["max_degree0"] > 32, "premise: lists wider than the M = 16 pipelines produce"

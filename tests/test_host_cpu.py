@@ -126,6 +126,15 @@ def test_error_conventions(hs, tmp_path):
     bad.write_bytes(open(os.path.join(GOLDEN, "l2_cont_d32.hnsw.bin"), "rb").read()[:5000])
     with pytest.raises(hs.HsError, match="corrupted"):
         hs.convert_slim(str(bad), str(tmp_path / "o.bin"), 32)
+    # the SlimQ graph harness follows the same conventions
+    with pytest.raises(hs.HsError, match="Cannot open file"):
+        hs.convert_slimq_graph(str(tmp_path / "nope.bin"), str(tmp_path / "o.bin"), 32)
+    with pytest.raises(hs.HsError, match="corrupted"):
+        hs.convert_slimq_graph(str(bad), str(tmp_path / "o.bin"), 32)
+    with pytest.raises(hs.HsError, match="M must be >= 2"):
+        hs.build_rabitq_hnsw(np.zeros((4, 64), np.float32), str(tmp_path / "o.bin"), M=1)
+    with pytest.raises(hs.HsError, match="bad metric"):
+        hs.build_rabitq_hnsw(np.zeros((4, 64), np.float32), str(tmp_path / "o.bin"), metric=7)
 
 
 def test_facade_error_conventions(hs):
