@@ -14,7 +14,7 @@ from bench import ground_truth, recall_at_k
 hs = load_product()
 which = sys.argv[1]
 if which == "gist":
-    n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 960, 1000
+    n, d, nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000, 960, int(os.environ.get("NQ", "1000"))   # configs[2]: batches of 1k
     G = [float(x) for x in os.environ.get("GEN", "4096,24,40,1.5").split(",")]   # calibrated in round 2 (profiles/r02_cfg_gist1m_d960.log)
     gen = lambda m, seed: np.clip(sift_like(m, d, seed, n_clusters=int(G[0]), rank=int(G[1]), sigma_sub=G[2], sigma_iso=G[3], integer=False) / 255.0, 0, 1).astype(np.float32)
 else:
