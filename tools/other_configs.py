@@ -94,6 +94,24 @@ for ef in [int(e) for e in os.environ.get('EFS', '32,64,128,192,256,384,512').sp
     if op is None and recall_at_k(L, gt) >= 0.95:
         op = (ef, recall_at_k(L, gt), nq / ms * 1e3, by.sum() / ms / 1e6)
 if op:
+    # the same operating point with 16 launches in flight on 16 streams (device-resident queries; what a serving loop sees: a
+    # launch smaller than the wave slots lasts as long as its longest query, several of them fill the chip)
+    ix.set_ef(op[0])
+    NS = 16
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    outs = [(torch.empty_like(lab), torch.empty_like(cnt)) for _ in range(NS)]
+    for st_, o_ in zip(streams, outs):
+        ix.search_ids_dev(qt, 10, o_[0], None, o_[1], None, st_.cuda_stream)
+    torch.cuda.synchronize(); t0 = time.time()
+    NB = 8 * NS
+    for r_ in range(NB):
+        st_, o_ = streams[r_ % NS], outs[r_ % NS]
+        ix.search_ids_dev(qt, 10, o_[0], None, o_[1], None, st_.cuda_stream)
+    torch.cuda.synchronize(); msp = (time.time() - t0) * 1e3 / NB
+    for st_ in streams: ix.check(st_.cuda_stream)
+    ix.search_ids_dev(qt, 10, lab, None, cnt, None, s); ix.check(s)
+    same_p = all(bool(torch.equal(o_[0], lab)) for o_ in outs)
+    print(f"PIPELINED {which} ef={op[0]}: {NS} launches of {nq} queries in flight: {nq/msp*1e3:.0f} q/s = {op[3] * ((nq/msp*1e3)/op[2]):.0f} alg GB/s = frac {op[3] * ((nq/msp*1e3)/op[2]) / 8000:.3f}; labels of all {NS} streams equal the single launch's: {same_p}", flush=True)
     open(os.path.join(idir, "operating_ef"), "w").write(str(op[0]))
     print(f"OPERATING POINT {which} n={n} d={d} nq={nq}: ef={op[0]} recall@10={op[1]:.4f} single-launch qps={op[2]:.0f} alg GB/s={op[3]:.0f} frac={op[3]/8000:.3f}", flush=True)
 else:

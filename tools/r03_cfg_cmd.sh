@@ -9,7 +9,7 @@ O=gpurun_out/r03_cfg_$W
 rm -rf $O; mkdir -p $O
 export IDX_DIR=/tmp/cfg_$W
 python -u tools/other_configs.py $W $N > $O/sweep.log 2>&1 || { tail -5 $O/sweep.log; kill $HB; exit 1; }
-cat $O/sweep.log | grep -v "^ef=.*oracle_match_first200=True" | tail -4; grep -c "oracle_match_first200=True" $O/sweep.log
+cat $O/sweep.log | grep -v "^ef=.*oracle_match_first200=True" | tail -5; grep -c "oracle_match_first200=True" $O/sweep.log
 EF=$(cat $IDX_DIR/operating_ef 2>/dev/null || echo 256)
 export PROFILE_EF=$EF
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python tools/other_configs.py $W $N > $O/kt.log 2>&1
