@@ -231,7 +231,9 @@ static FlatPlan plan_flat(const hs_index *ix, uint32_t ef, size_t nq) {
     static const size_t env_waves = getenv("HS_FLAT_WAVES_PER_CU") ? (size_t)atoi(getenv("HS_FLAT_WAVES_PER_CU")) : 0;   // diagnostic: builds with another residency
     const size_t max_waves = env_waves ? env_waves : flatk_waves_per_cu(dim, ef);
     size_t waves = std::min<size_t>(max_waves, kLdsPerCU / std::max<size_t>(total, 1));
-    waves = std::min(waves, std::max<size_t>((nq + 255) / 256, 1));   // a launch smaller than the wave slots: fewer, larger shares
+    // a launch smaller than the wave slots: fewer, larger shares (HS_FLAT_GROW=0: never -- diagnostic A/B knob)
+    static const bool grow = !(getenv("HS_FLAT_GROW") && atoi(getenv("HS_FLAT_GROW")) == 0);
+    if (grow) waves = std::min(waves, std::max<size_t>((nq + 255) / 256, 1));
     if (waves >= 1) {
       const size_t share = std::min<size_t>((kLdsPerCU / waves) & ~size_t(15), 64 * 1024);
       if (share > total) nb += (uint32_t)((share - total) / 16);
