@@ -214,8 +214,8 @@ static hs_status plan_shape(const hs_index *ix, size_t k, Shape &s) {
 }
 
 // Flat kernel (flat_search.hip): visited-set buckets, the division constants of bucket = h mod nb, and the LDS share of its
-// (lazily replayed) candidate heap.  The bucket count takes whatever LDS the wave's residency granule leaves unused: a launch
-// that fills the chip runs 5 wavefronts per SIMD = 20 workgroups per CU = 8 KiB each, a smaller launch fewer and larger ones.
+// (lazily replayed) candidate heap.  The bucket count takes whatever LDS the wave's residency granule leaves unused: 5 wavefronts
+// per SIMD = 20 workgroups per CU = 8 KiB each on the common shapes (flatk_waves_per_cu).
 struct FlatPlan { uint32_t nb, mul, sh, vis_bits; bool ok; };
 static FlatPlan plan_flat(const hs_index *ix, uint32_t ef, size_t nq) {
   FlatPlan f{};
@@ -231,9 +231,9 @@ static FlatPlan plan_flat(const hs_index *ix, uint32_t ef, size_t nq) {
     static const size_t env_waves = getenv("HS_FLAT_WAVES_PER_CU") ? (size_t)atoi(getenv("HS_FLAT_WAVES_PER_CU")) : 0;   // diagnostic: builds with another residency
     const size_t max_waves = env_waves ? env_waves : flatk_waves_per_cu(dim, ef);
     size_t waves = std::min<size_t>(max_waves, kLdsPerCU / std::max<size_t>(total, 1));
-    // a launch smaller than the wave slots: fewer, larger shares (HS_FLAT_GROW=0: never -- diagnostic A/B knob)
-    static const bool grow = !(getenv("HS_FLAT_GROW") && atoi(getenv("HS_FLAT_GROW")) == 0);
-    if (grow) waves = std::min(waves, std::max<size_t>((nq + 255) / 256, 1));
+    // (Until round 3 a launch smaller than the wave slots took fewer, larger shares.  Measured, profiles/r03_small_launch_lds_share_ab.log:
+    //  nothing gained on a single small launch -- 1250 SIFT queries 0.705 vs 0.655 ms, 1000 GIST queries 3.420 vs 3.416 ms -- and with
+    //  16 such launches in flight the larger shares cap the residency: 416 k vs 520 k q/s.  The share is the full-residency one.)
     if (waves >= 1) {
       const size_t share = std::min<size_t>((kLdsPerCU / waves) & ~size_t(15), 64 * 1024);
       if (share > total) nb += (uint32_t)((share - total) / 16);
