@@ -920,6 +920,21 @@ hs_status hs_search_batch_dev(hs_index *ix, const float *d_queries, size_t nq, s
 
 // H2D of the queries, the search, D2H of the requested outputs: all enqueued on `stream`, no host synchronisation.  The
 // staging buffers belong to (index, stream): a second call on the same stream reuses them in stream order.
+// The device's address of a host buffer that is page-locked AND mapped into the device's address space (hipHostMalloc /
+// hs_host_alloc, hipHostRegister with the mapped flag), or null: such a buffer needs no staging copy -- the kernels read the
+// queries from it and write the results into it directly.
+static void *mapped_device_pointer(const void *host) {
+  if (!host) return nullptr;
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // pageable memory
+  if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+  return at.devicePointer;
+}
+// A batch from page-locked host buffers, stream-ordered.  Results always go straight into mapped output buffers (a few dozen
+// bytes per query); the queries are read in place when the batch is small (<= kZeroCopyQueryBytes: every wavefront stages its
+// query once, and a small batch's copy engine round trips -- two per batch, each a cross-engine dependency in the stream -- cost
+// more than they move: 1250-query batches, 16 in flight, PCIe-inclusive: see DESIGN.md 6), through a staging copy otherwise.
+static constexpr size_t kZeroCopyQueryBytes = 1u << 20;
 static hs_status search_async(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *l32, uint64_t *l64,
                               float *dd, uint32_t *cnt, uint32_t *stats, hipStream_t st) {
   if (!ix || !queries) return fail(HS_ERR_INVALID, "null argument");
@@ -928,22 +943,35 @@ static hs_status search_async(hs_index *ix, const float *queries, size_t nq, siz
   HIP_TRY(hipSetDevice(ix->device));
   const size_t dim = ix->info.dim;
   hs_index::StreamWs *w = ix->stream_ws(st);
-  HIP_TRY(w->aq.ensure(nq * dim));
-  if (l32 || mode == HS_MODE_SLIM_IDS) HIP_TRY(w->al32.ensure(nq * k));
-  if (l64 || mode == HS_MODE_PQ) HIP_TRY(w->al64.ensure(nq * k));
-  if (dd || mode == HS_MODE_PQ) HIP_TRY(w->adist.ensure(nq * k));
-  HIP_TRY(w->acnt.ensure(nq));
-  if (stats) HIP_TRY(w->astats.ensure(nq * 4));
-  HIP_TRY(hipMemcpyAsync(w->aq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+  static const bool zero_copy_off = getenv("HS_ZERO_COPY") && atoi(getenv("HS_ZERO_COPY")) == 0;   // diagnostic A/B knob
   const bool ids = mode == HS_MODE_SLIM_IDS;
-  hs_status s = search_dev(ix, w->aq.p, nq, k, mode, (l32 || ids) ? w->al32.p : nullptr, (l64 || !ids) ? w->al64.p : nullptr,
-                           (dd || !ids) ? w->adist.p : nullptr, w->acnt.p, stats ? w->astats.p : nullptr, nullptr, nullptr, st);
+  const float *dq = nullptr;
+  if (!zero_copy_off && nq * dim * sizeof(float) <= kZeroCopyQueryBytes) dq = static_cast<const float *>(mapped_device_pointer(queries));
+  if (!dq) {
+    HIP_TRY(w->aq.ensure(nq * dim));
+    HIP_TRY(hipMemcpyAsync(w->aq.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    dq = w->aq.p;
+  }
+  // each output: the caller's buffer itself when the device can write it, else a device buffer + a copy back
+  auto direct = [&](void *host) -> void * { return zero_copy_off ? nullptr : mapped_device_pointer(host); };
+  uint32_t *o32 = static_cast<uint32_t *>(direct(l32));
+  uint64_t *o64 = static_cast<uint64_t *>(direct(l64));
+  float *odd = static_cast<float *>(direct(dd));
+  uint32_t *ocnt = static_cast<uint32_t *>(direct(cnt));
+  uint32_t *ost = static_cast<uint32_t *>(direct(stats));
+  const bool c32 = !o32 && (l32 || ids), c64 = !o64 && (l64 || !ids), cdd = !odd && (dd || !ids), ccnt = !ocnt, cst = !ost && stats;
+  if (c32) { HIP_TRY(w->al32.ensure(nq * k)); o32 = w->al32.p; }
+  if (c64) { HIP_TRY(w->al64.ensure(nq * k)); o64 = w->al64.p; }
+  if (cdd) { HIP_TRY(w->adist.ensure(nq * k)); odd = w->adist.p; }
+  if (ccnt) { HIP_TRY(w->acnt.ensure(nq)); ocnt = w->acnt.p; }
+  if (cst) { HIP_TRY(w->astats.ensure(nq * 4)); ost = w->astats.p; }
+  hs_status s = search_dev(ix, dq, nq, k, mode, o32, o64, odd, ocnt, ost, nullptr, nullptr, st);
   if (s != HS_OK) return s;
-  if (l32) HIP_TRY(hipMemcpyAsync(l32, w->al32.p, nq * k * 4, hipMemcpyDeviceToHost, st));
-  if (l64) HIP_TRY(hipMemcpyAsync(l64, w->al64.p, nq * k * 8, hipMemcpyDeviceToHost, st));
-  if (dd) HIP_TRY(hipMemcpyAsync(dd, w->adist.p, nq * k * 4, hipMemcpyDeviceToHost, st));
-  if (cnt) HIP_TRY(hipMemcpyAsync(cnt, w->acnt.p, nq * 4, hipMemcpyDeviceToHost, st));
-  if (stats) HIP_TRY(hipMemcpyAsync(stats, w->astats.p, nq * 16, hipMemcpyDeviceToHost, st));
+  if (c32 && l32) HIP_TRY(hipMemcpyAsync(l32, w->al32.p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  if (c64 && l64) HIP_TRY(hipMemcpyAsync(l64, w->al64.p, nq * k * 8, hipMemcpyDeviceToHost, st));
+  if (cdd && dd) HIP_TRY(hipMemcpyAsync(dd, w->adist.p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  if (ccnt && cnt) HIP_TRY(hipMemcpyAsync(cnt, w->acnt.p, nq * 4, hipMemcpyDeviceToHost, st));
+  if (cst && stats) HIP_TRY(hipMemcpyAsync(stats, w->astats.p, nq * 16, hipMemcpyDeviceToHost, st));
   return HS_OK;
 }
 

@@ -283,3 +283,35 @@ np.savez(sys.argv[3], l=np.sort(r["labels"], 1), d=np.sort(r["dists"], 1), s=r["
     assert str(res["lean_big"]["k"][0]) == "hs::lean_kernel" and str(res["default"]["k"][0]) == "hs::flat_kernel"
     for key in ("l", "d", "s"):
         assert np.array_equal(res["default"][key], res["lean_big"][key]), key
+
+
+def test_async_entry_reads_and_writes_mapped_host_buffers_in_place(hs, slim_file):
+    """hs_search_batch_async with page-locked (device-mapped) buffers: results land in the caller's buffer without a copy back,
+    small batches are read in place (<= 1 MiB of queries), larger ones through the staging copy; views at an offset inside the
+    allocation and pageable (unmapped) buffers take whichever path applies -- all equal to the synchronous call."""
+    import torch
+    ix = hs.Index(slim_file, hs.HS_KIND_SLIM, 32)
+    ix.set_ef(40)
+    st = torch.cuda.Stream()
+    for nq, off in ((300, 0), (300, 7), (9000, 0), (9000, 3)):   # 9000 x 32 floats = 1.1 MiB: staged
+        base_q = mixture(nq + off, 32, 91 + nq + off)
+        qp, op, dp, cp = hs.PinnedArray((nq + off, 32), np.float32), hs.PinnedArray((nq + off, 10), np.uint32), hs.PinnedArray((nq + off, 10), np.float32), hs.PinnedArray((nq + off,), np.uint32)
+        qp.a[:] = base_q
+        op.a[:] = 0xFFFFFFFF
+        dp.a[:] = -1.0
+        cp.a[:] = 77
+        ix.search_ids_async(qp.a[off:], 10, op.a[off:], st.cuda_stream, dists_pinned=dp.a[off:], counts_pinned=cp.a[off:])
+        ix.check(st.cuda_stream)
+        want = ix.search_ids(base_q[off:], 10, want_dists=True)
+        assert np.array_equal(op.a[off:], want["labels"]), (nq, off)
+        assert np.array_equal(dp.a[off:].view(np.uint32), want["dists"].view(np.uint32)), (nq, off)
+        assert np.all(cp.a[off:] == 10) and np.all(op.a[:off] == 0xFFFFFFFF) and np.all(cp.a[:off] == 77), (nq, off)
+        # pageable output buffer with a mapped query buffer, and the other way round
+        lab = np.zeros((nq, 10), np.uint32)
+        ix.search_ids_async(qp.a[off:], 10, lab, st.cuda_stream)
+        ix.check(st.cuda_stream)
+        assert np.array_equal(lab, want["labels"]), (nq, off)
+        op.a[:] = 0
+        ix.search_ids_async(np.ascontiguousarray(base_q[off:]), 10, op.a[off:], st.cuda_stream)
+        ix.check(st.cuda_stream)
+        assert np.array_equal(op.a[off:], want["labels"]), (nq, off)
