@@ -293,7 +293,7 @@ def test_async_entry_reads_and_writes_mapped_host_buffers_in_place(hs, slim_file
     ix = hs.Index(slim_file, hs.HS_KIND_SLIM, 32)
     ix.set_ef(40)
     st = torch.cuda.Stream()
-    for nq, off in ((300, 0), (300, 7), (9000, 0), (9000, 3)):   # 9000 x 32 floats = 1.1 MiB: staged
+    for nq, off in ((300, 0), (300, 7), (9000, 0), (9000, 3)):   # 9000 x 32 floats = 1.1 MiB: staged both ways
         base_q = mixture(nq + off, 32, 91 + nq + off)
         qp, op, dp, cp = hs.PinnedArray((nq + off, 32), np.float32), hs.PinnedArray((nq + off, 10), np.uint32), hs.PinnedArray((nq + off, 10), np.float32), hs.PinnedArray((nq + off,), np.uint32)
         qp.a[:] = base_q
