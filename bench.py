@@ -67,6 +67,18 @@ def checksum(labels):
     return int(v.sum()), int(np.bitwise_xor.reduce(v))
 
 
+def hip_queue_hint(nq, world, scaling):
+    """Many SMALL launches in flight (a strong split's per-rank shards: 10 000 / 8 = 1250 queries) are held back by the HIP
+    runtime's default of 4 hardware queues, onto which the 16 streams are multiplexed: measured on one MI355X with 1250-query
+    batches, 16 in flight, PCIe-inclusive: 5.65 M q/s with 4 queues, 8.36 M with 8, 9.77 M with 16 (profiles/r03_small_batch_queues.log);
+    10k-query batches prefer the default (13.8 vs 13.0 M q/s).  The variable is read when the HIP runtime initialises, so it is
+    set here, before torch is imported, and only when the caller has not set it."""
+    strong = scaling == "strong" or (scaling == "auto" and world > 1)
+    per_rank = nq // world if strong else nq
+    if per_rank <= 2500:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +99,7 @@ def main():
     ap.add_argument("--query-sets", type=int, default=8, help="distinct pre-generated query batches rotated through")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto", help="auto: strong (one batch split over the ranks) when --gpus > 1")
     args = ap.parse_args()
+    hip_queue_hint(args.nq, int(os.environ.get("WORLD_SIZE", "1")), args.scaling)
 
     import torch
     import torch.distributed as dist
@@ -431,6 +444,7 @@ def main():
                                + ("RCCL all-gather of the labels + " if world > 1 else "") + "D2H of the labels; every batch's labels are checked (checksum) before its buffer is reused",
                        "batches_timed": n_batches, "ms_per_batch": round(batch_ms, 4), "timed_seconds": round(elapsed, 3),
                        "pipelining": f"batches issued round-robin on {S} HIP streams (up to {S} in flight)",
+                       "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "entry": "hs_search_batch_async (host pointers)" if world == 1 else "hs_search_batch_dev + torch.distributed all_gather_into_tensor",
                        "ef_search": chosen, "recall_at_10": round(recall, 4), "recall_per_query_set": [round(r, 4) for r in recalls],
                        "sweep": sweep, "index": info, "build_s": round(t_build, 1), "convert_s": round(t_conv, 1), "build_threads": threads,

@@ -944,7 +944,8 @@ static hs_status search_async(hs_index *ix, const float *queries, size_t nq, siz
   HIP_TRY(hipSetDevice(ix->device));
   const size_t dim = ix->info.dim;
   hs_index::StreamWs *w = ix->stream_ws(st);
-  static const bool zero_copy_off = getenv("HS_ZERO_COPY") && atoi(getenv("HS_ZERO_COPY")) == 0;   // diagnostic A/B knob
+  static const bool zero_copy_off = getenv("HS_ZERO_COPY") && !strcmp(getenv("HS_ZERO_COPY"), "0");      // diagnostic A/B knobs
+  static const bool zero_copy_in_only = getenv("HS_ZERO_COPY") && !strcmp(getenv("HS_ZERO_COPY"), "in");   // (outputs staged)
   const bool ids = mode == HS_MODE_SLIM_IDS;
   const float *dq = nullptr;
   if (!zero_copy_off && nq * dim * sizeof(float) <= kZeroCopyQueryBytes) dq = static_cast<const float *>(mapped_device_pointer(queries));
@@ -956,7 +957,7 @@ static hs_status search_async(hs_index *ix, const float *queries, size_t nq, siz
   // each output: the caller's buffer itself when the device can write it (small batches, as for the queries: with 10k-query
   // batches the staged path measured 2 % faster), else a device buffer + a copy back
   const bool small = nq * dim * sizeof(float) <= kZeroCopyQueryBytes;
-  auto direct = [&](void *host) -> void * { return (zero_copy_off || !small) ? nullptr : mapped_device_pointer(host); };
+  auto direct = [&](void *host) -> void * { return (zero_copy_off || zero_copy_in_only || !small) ? nullptr : mapped_device_pointer(host); };
   uint32_t *o32 = static_cast<uint32_t *>(direct(l32));
   uint64_t *o64 = static_cast<uint64_t *>(direct(l64));
   float *odd = static_cast<float *>(direct(dd));
