@@ -27,7 +27,7 @@ EXPORTS = [
     "hs_slimq_search_batch", "hs_slimq_search_batch_dev", "hs_slimq_trace", "hs_slimq_prepare_debug", "hs_brute_force", "hs_brute_force_dev",
     "hs_search_batch_async", "hs_host_alloc", "hs_host_free", "hs_comm_init", "hs_comm_free", "hs_comm_size", "hs_search_batch_sharded",
     "hs_comm_results_dev", "hs_convert_slim_gpu", "hs_index_patch", "hs_index_from_host_arrays", "hs_build_rabitq_hnsw",
-    "hs_convert_slimq_graph",
+    "hs_convert_slimq_graph", "hs_host_device_pointer",
 ]
 
 
@@ -102,6 +102,8 @@ def lib():
     L.hs_build_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, ctypes.c_char_p, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ctypes.c_char_p]
     L.hs_convert_slimq_graph.argtypes = L.hs_convert_slim.argtypes
+    L.hs_host_device_pointer.restype = ctypes.c_void_p
+    L.hs_host_device_pointer.argtypes = [vp]
     L.hs_build_rabitq_hnsw.argtypes = [vp, sz, sz, ci, sz, sz, sz, ci, ctypes.c_char_p]
     L.hs_convert_slim_gpu.argtypes = [ctypes.c_char_p, ci, sz, ci, ctypes.c_float, ctypes.c_float, sz, sz, sz, sz, ci, ci, ctypes.c_char_p,
                                       ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
@@ -273,6 +275,22 @@ class PinnedArray:
             raise HsError(HS_ERR_NOMEM, "hs_host_alloc failed")
         buf = (ctypes.c_char * max(self.nbytes, 1)).from_address(self.ptr)
         self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def device_view(self, rows=None):
+        """An object search_ids_dev accepts as d_queries: the device's address of this buffer (hs_host_device_pointer) -- the kernels
+        then read the queries in place instead of from a staged copy.  None when the buffer is not device-mapped."""
+        p = lib().hs_host_device_pointer(self.ptr)
+        if not p:
+            return None
+        shape = self.a.shape if rows is None else (rows,) + tuple(self.a.shape[1:])
+
+        class _View:
+            def __init__(v):
+                v.shape = shape
+
+            def data_ptr(v):
+                return p
+        return _View()
 
     def __del__(self):
         try:

@@ -1039,6 +1039,7 @@ void *hs_host_alloc(size_t bytes) {
 void hs_host_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
+void *hs_host_device_pointer(const void *host) { return mapped_device_pointer(host); }
 
 hs_status hs_search_batch(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *out_labels32,
                           uint64_t *out_labels64, float *out_dists, uint32_t *out_counts, uint32_t *stats) {

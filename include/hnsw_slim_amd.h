@@ -163,6 +163,10 @@ hs_status hs_search_batch_async(hs_index *ix, const float *queries, size_t nq, s
                                 uint32_t *out_counts, uint32_t *stats, void *stream);
 void *hs_host_alloc(size_t bytes);   /* page-locked host memory (NULL on failure) */
 void hs_host_free(void *p);
+/* The device's address of a page-locked host buffer that is mapped into the device's address space (hs_host_alloc, hipHostMalloc,
+ * mapped hipHostRegister), or NULL (pageable memory).  hs_search_batch_async serves small batches from such buffers in place;
+ * a caller of hs_search_batch_dev may pass this address as d_queries for the same effect (the kernels read each query once). */
+void *hs_host_device_pointer(const void *host);
 
 /* ---- multi-GPU (no counterpart in the reference, which has no notion of a device) --------------------
  * Queries are independent and the index is read-only during search: the index is REPLICATED (hs_index_load once per
