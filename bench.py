@@ -72,11 +72,13 @@ def hip_queue_hint(nq, world, scaling):
     runtime's default of 4 hardware queues, onto which the 16 streams are multiplexed: measured on one MI355X with 1250-query
     batches, 16 in flight, PCIe-inclusive: 5.65 M q/s with 4 queues, 8.36 M with 8, 9.77 M with 16 (profiles/r03_small_batch_queues.log);
     10k-query batches prefer the default (13.8 vs 13.0 M q/s).  The variable is read when the HIP runtime initialises, so it is
-    set here, before torch is imported, and only when the caller has not set it."""
+    set here, before torch is imported, and only when the caller has not set it.  One process per GPU gets 8 (RCCL brings queues
+    of its own, and a device whose hardware queues are oversubscribed time-slices them: two rank processes REHEARSING on one GPU
+    with 16 queues each fell to 9 k q/s -- which is why the one-device rehearsal is left alone); a single process gets 16."""
     strong = scaling == "strong" or (scaling == "auto" and world > 1)
     per_rank = nq // world if strong else nq
-    if per_rank <= 2500:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    if per_rank <= 2500 and os.environ.get("HS_BENCH_ONE_DEVICE") != "1":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if world == 1 else "8")
 
 
 def main():
