@@ -988,6 +988,7 @@ static hipError_t flat_launch_d(const DevIndex &ix, const SearchArgs &a, hipStre
   const size_t lds = flat_layout(ix.dim, a.ef, a.fl_nb).total;
   if (a.ef <= 64) return flat_launch(flat_kernel<METRIC, 1, D16>, ix, a, lds, stream);
   if (a.ef <= 128) return flat_launch(flat_kernel<METRIC, 2, D16>, ix, a, lds, stream);
+  if (a.ef <= 192) return flat_launch(flat_kernel<METRIC, 3, D16>, ix, a, lds, stream);   // (three slots instead of four: ef = 160 +5.5 %, 192 +3.5 %)
   if (a.ef <= 256) return flat_launch(flat_kernel<METRIC, 4, D16>, ix, a, lds, stream);
   if (a.ef <= 384) return flat_launch(flat_kernel<METRIC, 6, D16>, ix, a, lds, stream);
   return flat_launch(flat_kernel<METRIC, 8, D16>, ix, a, lds, stream);
@@ -1049,7 +1050,7 @@ bool flatk_supported(const DevIndex &ix, uint32_t ef, uint32_t k) {
 }
 // wavefronts per CU the shape's kernel is resident with (the LDS share of a wave follows from it: capi.cpp plan_flat)
 uint32_t flatk_waves_per_cu(uint32_t dim, uint32_t ef) {
-  const int s = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 384 ? 6 : 8;
+  const int s = ef <= 64 ? 1 : ef <= 128 ? 2 : ef <= 192 ? 3 : ef <= 256 ? 4 : ef <= 384 ? 6 : 8;
   const int d16 = dim == 128 ? 8 : dim == 96 ? 6 : dim == 960 ? 60 : dim > 256 ? -1 : 0;
   return 4u * (uint32_t)flat_waves(s, d16);
 }

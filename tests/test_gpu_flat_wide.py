@@ -1,4 +1,5 @@
-"""The flat kernel's wide shapes (csrc/flat_search.hip): result sets beyond 256 entries (S = 6 for ef <= 384, S = 8 for ef <= 512)
+"""The flat kernel's wide shapes (csrc/flat_search.hip): three slots per lane (ef 129..192, exact fit at 192), result sets beyond 256
+entries (S = 6 for ef <= 384, S = 8 for ef <= 512)
 and rows beyond 1 KB (d = 960 compiled in: two rounds of thirty 8-byte loads per lane; any other dim > 256: rounds of sixteen),
 against the oracle (hnswalg_slim.h:321-457 / hnswalg.h:326-479): labels, fp32 distance bits, the three traversal counters, on
 tie-heavy integer rows and on continuous ones, L2 and inner product, Slim and vanilla files."""
@@ -38,7 +39,7 @@ def test_flat_kernel_wide_result_sets_and_long_rows(env, tmp_path, d, metric, in
     for kind, path, okind in ((P.HS_KIND_SLIM, sp, "slim"), (P.HS_KIND_HNSW, hp, "hnsw")):
         ix = P.Index(path, kind, d, metric=metric)
         ox = O.load(path, okind, metric, d)
-        for ef, k in ((257, 10), (320, 40), (384, 10), (385, 64), (500, 10), (512, 64)) if kind == P.HS_KIND_SLIM else ((300, 10), (512, 20)):
+        for ef, k in ((129, 10), (160, 33), (192, 64), (257, 10), (320, 40), (384, 10), (385, 64), (500, 10), (512, 64)) if kind == P.HS_KIND_SLIM else ((192, 10), (300, 10), (512, 20)):
             cfg = f"d={d} metric={metric} int={integer} kind={okind} ef={ef} k={k}"
             ix.set_ef(ef); ox.set_ef(ef)
             o, g = ox.search_pq(q, k, threads=8), ix.search_pq(q, k, want_stats=True)
