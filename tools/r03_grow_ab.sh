@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3 A/B: should a launch smaller than the wave slots take a larger LDS share per query (HS_FLAT_GROW, capi.cpp plan_flat)?
+# round 3 A/B (historical: the HS_FLAT_GROW knob existed for this run only and the growth it switched was removed afterwards): should a launch smaller
+# than the wave slots take a larger LDS share per query (capi.cpp plan_flat)?
 # (a) GIST-like d=960, 1k-query launches: single launch and 16 in flight; (b) SIFT-like bench index, 1250-query launches (flat_diag.py)
 export TMPDIR=/tmp
 ( while true; do sleep 60; date >> gpurun_out/heartbeat.log; done ) &
