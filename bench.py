@@ -185,7 +185,7 @@ def main():
     # ---- rank 0 only: ground truth, the ef sweep on query set 0 (device-resident, one launch at a time), the operating point:
     #      the smallest sweep ef whose recall@10 >= 0.95 over ALL the query sets of the timed region --------------------------
     sweep, chosen, recall, recalls = {}, 0, 0.0, []
-    efs = [args.ef] if args.ef else [32, 48, 64, 68, 70, 72, 80, 96, 128, 192, 256]
+    efs = [args.ef] if args.ef else [32, 48, 64, 68, 70, 72, 80, 96, 128, 192, 256, 384, 512]
     if rank == 0:
         base_t = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
         gts = [ground_truth(torch, base_t, q, K, hs) for q in q_sets_t]
