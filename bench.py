@@ -272,10 +272,10 @@ def main():
             # one rank per GPU: H2D, hs_search_batch_dev, RCCL all-gather of the labels, D2H of the gathered [tot x K]
             q_pin = [torch.from_numpy(query_sets[b][lo:hi].copy()).pin_memory() for b in range(NB)]
             q_dev = [torch.empty((rows, D), dtype=torch.float32, device=dev) for _ in range(S)]
-            # small shards (up to 1 MiB of queries, as hs_search_batch_async does it): no staging copy -- the kernels read each
+            # small shards (up to 2 MiB of queries, as hs_search_batch_async does it): no staging copy -- the kernels read each
             # query once from a device-mapped page-locked buffer (hs_host_alloc), see profiles/r03_small_batch_queues.log
             q_map = None
-            if 0 < rows * D * 4 <= (1 << 20) and os.environ.get("HS_ZERO_COPY", "1") != "0":
+            if 0 < rows * D * 4 <= (2 << 20) and os.environ.get("HS_ZERO_COPY", "1") != "0":
                 q_hold = [hs.PinnedArray((rows, D), np.float32) for _ in range(NB)]
                 for b in range(NB):
                     q_hold[b].a[:] = query_sets[b][lo:hi]
@@ -458,7 +458,7 @@ def main():
                        "batches_timed": n_batches, "ms_per_batch": round(batch_ms, 4), "timed_seconds": round(elapsed, 3),
                        "pipelining": f"batches issued round-robin on {S} HIP streams (up to {S} in flight)",
                        "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
-                       "entry": "hs_search_batch_async (host pointers)" if world == 1 else "hs_search_batch_dev + torch.distributed all_gather_into_tensor" + (" (queries read in place from mapped page-locked memory)" if (strong and 0 < rows * D * 4 <= (1 << 20)) else ""),
+                       "entry": "hs_search_batch_async (host pointers)" if world == 1 else "hs_search_batch_dev + torch.distributed all_gather_into_tensor" + (" (queries read in place from mapped page-locked memory)" if (strong and 0 < rows * D * 4 <= (2 << 20)) else ""),
                        "ef_search": chosen, "recall_at_10": round(recall, 4), "recall_per_query_set": [round(r, 4) for r in recalls],
                        "sweep": sweep, "index": info, "build_s": round(t_build, 1), "convert_s": round(t_conv, 1), "build_threads": threads,
                        "device_resident_pipelined_qps": round(dev_resident_qps, 1), "single_launch_qps": round(NQ / kern_ms * 1e3, 1),

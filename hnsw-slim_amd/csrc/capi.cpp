@@ -935,7 +935,7 @@ static void *mapped_device_pointer(const void *host) {
 // into the caller's -- a small batch's copy-engine round trips (two per batch, each a cross-engine dependency in the stream)
 // cost more than they move: 1250-query batches, 16 in flight, PCIe-inclusive 5.22 -> 5.65 M q/s.  Larger batches go through
 // the staging copies (10k-query batches: 13.9 vs 13.6 M q/s in favour of staging).
-static constexpr size_t kZeroCopyQueryBytes = 1u << 20;
+static constexpr size_t kZeroCopyQueryBytes = 2u << 20;
 static hs_status search_async(hs_index *ix, const float *queries, size_t nq, size_t k, int mode, uint32_t *l32, uint64_t *l64,
                               float *dd, uint32_t *cnt, uint32_t *stats, hipStream_t st) {
   if (!ix || !queries) return fail(HS_ERR_INVALID, "null argument");

@@ -158,7 +158,7 @@ hs_status hs_debug_heap_ops(const uint32_t *ops, size_t n_ops, int wave_pop, uin
  * kernels.  queries and outputs should be page-locked (hs_host_alloc, or hipHostMalloc / hipHostRegister of the
  * caller's own buffers): with pageable memory the copies are staged synchronously.  Staging buffers are per
  * (index, stream): do not reuse a stream for a second call on the same index before the first one's outputs are read.
- * Small batches (up to 1 MiB of queries) in device-mapped page-locked buffers are served IN PLACE: no staging copies, the
+ * Small batches (up to 2 MiB of queries) in device-mapped page-locked buffers are served IN PLACE: no staging copies, the
  * kernels read each query from `queries` and write the results into the output buffers directly -- so `queries` must stay
  * unchanged, and the outputs unread, until the batch has completed on `stream` (as for the copies, only for longer). */
 hs_status hs_search_batch_async(hs_index *ix, const float *queries, size_t nq, size_t k, int mode,

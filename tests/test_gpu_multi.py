@@ -287,13 +287,13 @@ np.savez(sys.argv[3], l=np.sort(r["labels"], 1), d=np.sort(r["dists"], 1), s=r["
 
 def test_async_entry_reads_and_writes_mapped_host_buffers_in_place(hs, slim_file):
     """hs_search_batch_async with page-locked (device-mapped) buffers: results land in the caller's buffer without a copy back,
-    small batches are read in place (<= 1 MiB of queries), larger ones through the staging copy; views at an offset inside the
+    small batches are read in place (<= 2 MiB of queries), larger ones through the staging copy; views at an offset inside the
     allocation and pageable (unmapped) buffers take whichever path applies -- all equal to the synchronous call."""
     import torch
     ix = hs.Index(slim_file, hs.HS_KIND_SLIM, 32)
     ix.set_ef(40)
     st = torch.cuda.Stream()
-    for nq, off in ((300, 0), (300, 7), (9000, 0), (9000, 3)):   # 9000 x 32 floats = 1.1 MiB: staged both ways
+    for nq, off in ((300, 0), (300, 7), (20000, 0), (20000, 3)):   # 20000 x 32 floats = 2.4 MiB: staged both ways
         base_q = mixture(nq + off, 32, 91 + nq + off)
         qp, op, dp, cp = hs.PinnedArray((nq + off, 32), np.float32), hs.PinnedArray((nq + off, 10), np.uint32), hs.PinnedArray((nq + off, 10), np.float32), hs.PinnedArray((nq + off,), np.uint32)
         qp.a[:] = base_q
